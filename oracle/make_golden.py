@@ -1,0 +1,128 @@
+"""ORACLE — TEST INFRASTRUCTURE. Generates tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference, CPU fp32) on seeded synthetic weights/inputs.  Run here (the GPU box has no reference):
+
+    python -m oracle.make_golden tiny            # seconds..minutes
+    python -m oracle.make_golden full_modules    # full-size nets, module level (a few minutes)
+    python -m oracle.make_golden full_pipeline   # 1x512x512, 50 spaced steps + CFG (≈10 min on 8 cores)
+
+Fixtures hold only outputs + token ids (+ tiny inputs); weights/inputs are re-derived from seeds by
+oracle/cases.py on both sides.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import cases
+from .ref_import import load_reference
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def build_reference(R, cfg_name: str, diffusion: dict, seed: int = 0):
+    cldm_cfg, swin_cfg = cases.get_cfgs(cfg_name)
+    W = cases.synth_weights(cldm_cfg, swin_cfg, seed)
+    with cases.quiet():
+        cldm = R.ControlLDM(**cldm_cfg).eval()
+        swin = R.SwinIR(**swin_cfg).eval()
+    cldm.unet.load_state_dict(W["unet"], strict=True)
+    cldm.controlnet.load_state_dict(W["controlnet"], strict=True)
+    cldm.vae.load_state_dict(W["vae"], strict=True)
+    cldm.clip.load_state_dict(W["clip"], strict=True)
+    missing, unexpected = swin.load_state_dict(W["swinir"], strict=False)
+    assert not unexpected and all(k.endswith(("attn_mask", "relative_position_index")) for k in missing), missing
+    diff = R.Diffusion(**diffusion)
+    return cldm, swin, diff, W
+
+
+def tokens_of(R, prompts):
+    from diffbir.model.open_clip import tokenize
+    return tokenize(list(prompts))
+
+
+def run_pipeline(R, cldm, swin, diff, lq, steps, sampler, seed, cfg=4.0, tiled=False, tile=512, stride=256,
+                 cleaner_tiled=False):
+    pipe = R.SwinIRPipeline(swin, cldm, diff, None, "cpu")
+    torch.manual_seed(seed)
+    with cases.quiet():
+        return pipe.run(lq, steps, 1.0, cleaner_tiled, 512, 256, False, 256, False, 256, tiled, tile, stride,
+                        "", cases.NEG_PROMPT, cfg, "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
+
+
+@torch.no_grad()
+def gen_modules(R, cfg_name: str, tag: str, img: int, diffusion):
+    cldm, swin, diff, W = build_reference(R, cfg_name, diffusion)
+    g = {}
+    rs = cases.NoiseStream(7)
+    x = torch.tensor(cases.make_lq(11, 2, img, img)).float().div(255).permute(0, 3, 1, 2).contiguous()
+    g["swinir_out"] = swin(x).numpy()
+    g["vae_mode"] = cldm.vae_encode(x * 2 - 1, sample=False).numpy()
+    z = rs((2, 4, img // 8, img // 8))
+    g["vae_dec"] = cldm.vae_decode(z).numpy()
+    toks = tokens_of(R, ["", cases.NEG_PROMPT])
+    g["tokens"] = toks.numpy()
+    c_txt = cldm.clip(toks)
+    g["c_txt"] = c_txt.numpy()
+    xn = rs((2, 4, img // 8, img // 8))
+    c_img = rs((2, 4, img // 8, img // 8)) * 0.5
+    cldm.control_scales = [0.9] * 13
+    t_int = torch.tensor([999, 381], dtype=torch.long)
+    g["eps_int_t"] = cldm(xn, t_int, dict(c_txt=c_txt, c_img=c_img)).numpy()
+    t_f = torch.tensor([949.0365, 49.95], dtype=torch.float32)
+    g["eps_float_t"] = cldm(xn, t_f, dict(c_txt=c_txt, c_img=c_img)).numpy()
+    ctrl = cldm.controlnet(x=xn, hint=c_img, timesteps=t_int, context=c_txt)
+    g["control_0"] = ctrl[0].numpy()
+    g["control_12"] = ctrl[12].numpy()
+    np.savez_compressed(os.path.join(OUT, f"{tag}_modules.npz"), **g)
+    print(tag, "modules done", {k: v.shape for k, v in g.items()})
+
+
+@torch.no_grad()
+def gen_tiny_pipelines(R):
+    g = {}
+    for ver, dcfg in (("v21", "DIFFUSION_V21"), ("v2", "DIFFUSION_V2")):
+        from diffbir_amd import configs
+        cldm, swin, diff, W = build_reference(R, "tiny", configs.get(dcfg))
+        lq = cases.make_lq(3, 1, 512, 512)
+        g[f"spaced6_{ver}"] = run_pipeline(R, cldm, swin, diff, lq, 6, "spaced", 231)
+        if ver == "v21":
+            g["dpm10_v21"] = run_pipeline(R, cldm, swin, diff, lq, 10, "dpm++_m2", 231)
+            lq2 = cases.make_lq(5, 2, 512, 512)
+            g["spaced4_b2_v21"] = run_pipeline(R, cldm, swin, diff, lq2, 4, "spaced", 99)
+            lq3 = cases.make_lq(9, 1, 600, 712)  # not multiples of 64/8: pad paths + edge-flush tile windows
+            g["spaced3_pad_v21"] = run_pipeline(R, cldm, swin, diff, lq3, 3, "spaced", 5)
+            g["spaced3_tiled_v21"] = run_pipeline(R, cldm, swin, diff, lq3, 3, "spaced", 5, tiled=True)
+            g["dpm10_tiled_v21"] = run_pipeline(R, cldm, swin, diff, lq3, 10, "dpm++_m2", 5, tiled=True)
+        else:
+            g["dpm10_v2"] = run_pipeline(R, cldm, swin, diff, lq, 10, "dpm++_m2", 231)
+    np.savez_compressed(os.path.join(OUT, "tiny_pipeline.npz"), **g)
+    print("tiny pipelines done", {k: v.shape for k, v in g.items()})
+
+
+@torch.no_grad()
+def gen_full_pipeline(R):
+    from diffbir_amd import configs
+    cldm, swin, diff, W = build_reference(R, "full", configs.get("DIFFUSION_V21"))
+    lq = cases.make_lq(3, 1, 512, 512)
+    t0 = time.time()
+    out = run_pipeline(R, cldm, swin, diff, lq, 50, "spaced", 231)
+    dt = time.time() - t0
+    np.savez_compressed(os.path.join(OUT, "full_pipeline.npz"), spaced50_v21=out,
+                        ref_cpu_seconds=np.float64(dt), ref_cpu_threads=np.int64(torch.get_num_threads()))
+    print("full pipeline done in", dt, "s")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    what = sys.argv[1]
+    R = load_reference()
+    from diffbir_amd import configs
+    if what == "tiny":
+        gen_modules(R, "tiny", "tiny", 128, configs.get("DIFFUSION_V21"))
+        gen_tiny_pipelines(R)
+    elif what == "full_modules":
+        gen_modules(R, "full", "full", 256, configs.get("DIFFUSION_V21"))
+    elif what == "full_pipeline":
+        gen_full_pipeline(R)
