@@ -1,0 +1,202 @@
+// Flash-style attention forward for head_dim 64 on gfx950 MFMA (no mask), see include/dbir.h.
+//
+// Work decomposition: grid = (ceil(Lq/128), B*H); 256 threads = 4 wave64; each wave owns 32 query rows and
+// walks the keys in tiles of 64 that the whole block stages through LDS.
+//
+// The score tile is computed TRANSPOSED, S^T = K Q^T (A-operand = K rows from LDS, B-operand = Q rows held
+// in registers), so that with the 32x32x16 C/D layout (col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)) every
+// lane holds 32 of the 64 scores of ONE query (the other 32 live in lane^32): the online-softmax row max / row
+// sum are 31 in-register ops plus one cross-half shuffle, and the O^T accumulator rescale is lane-local.
+//
+// P feeds the second MFMA (O^T += V^T P^T) straight from the accumulator registers: for key-step s the
+// B-operand element j of half `hi` is accumulator register 8*(s&1)+j of score block s>>1, which corresponds
+// to key 16*s + 4*hi + (j&3) + 8*(j>>2).  The contraction index of an MFMA is arbitrary as long as both
+// operands agree, so V^T is read from LDS with exactly that key permutation (two ds_read_b64 per step) and
+// no cross-lane shuffles or LDS round trip for P are needed.  V arrives already transposed ([d][key], emitted
+// by the producing GEMM's transposed store) so both LDS images are filled with coalesced 16-byte rows.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;        // keys per tile
+constexpr int K_LD = 64 + 8;  // K tile row (halfs): 144 B -> conflict-free ds_read_b128
+constexpr int V_LD = 64 + 4;  // V^T tile row (halfs): 136 B -> conflict-free ds_read_b64
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ Q, long long q_bs, long long ldq,
+                                                   const u16* __restrict__ K, long long k_bs, long long ldk,
+                                                   const u16* __restrict__ Vt, long long vt_bs, long long ldvt,
+                                                   u16* __restrict__ O, long long o_bs, long long ldo, int H,
+                                                   int Lq, int Lk, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) u16 Ks[KT * K_LD];
+  __shared__ __attribute__((aligned(16))) u16 Vs[64 * V_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int q_row = blockIdx.x * 128 + wave * 32 + lq;
+  const bool q_ok = q_row < Lq;
+
+  // Q fragments (B operand): lane holds Q[q][16*ks + 8*hi .. +7], ks = 0..3
+  typename T::vec8 qf[4];
+  {
+    const u16* qp = Q + (long long)b * q_bs + (long long)(q_ok ? q_row : 0) * ldq + h * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 v = q_ok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
+      qf[ks] = __builtin_bit_cast(typename T::vec8, v);
+    }
+  }
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const u16* Kg = K + (long long)b * k_bs + h * 64;
+  const u16* Vg = Vt + (long long)b * vt_bs + (long long)(h * 64) * ldvt;
+  const int kc = tid & 7, r0 = tid >> 3;  // staging: 16-byte chunk kc of row r0 (+32)
+
+  const int ntiles = (Lk + KT - 1) / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int key0 = kt * KT;
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K tile [key][d] and V^T tile [d][key] ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = r0 + 32 * i;
+      const int key = key0 + row;
+      uint4 kv = make_uint4(0, 0, 0, 0);
+      if (key < Lk) kv = *reinterpret_cast<const uint4*>(Kg + (long long)key * ldk + kc * 8);
+      *reinterpret_cast<uint4*>(&Ks[row * K_LD + kc * 8]) = kv;
+      // V^T: row = d, chunk = keys key0 + kc*8 .. +7
+      const int kcol = key0 + kc * 8;
+      uint4 vv = make_uint4(0, 0, 0, 0);
+      if (kcol < Lk) {
+        vv = *reinterpret_cast<const uint4*>(Vg + (long long)row * ldvt + kcol);
+        if (kcol + 8 > Lk) {  // zero the tail beyond Lk (pad columns may hold anything)
+          u16* hv = reinterpret_cast<u16*>(&vv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (kcol + e >= Lk) hv[e] = 0;
+        }
+      }
+      // V_LD rows are 8-byte aligned only: write as two 8-byte halves
+      uint2* dst = reinterpret_cast<uint2*>(&Vs[row * V_LD + kc * 8]);
+      dst[0] = make_uint2(vv.x, vv.y);
+      dst[1] = make_uint2(vv.z, vv.w);
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T : two 32-key blocks x 4 d-steps ----
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        typename T::vec8 kf =
+            *reinterpret_cast<const typename T::vec8*>(&Ks[(kb * 32 + lq) * K_LD + ks * 16 + hi * 8]);
+        s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
+      }
+    }
+    // ---- online softmax (log2 domain) ----
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float sv = s_acc[kb][r] * scale_log2e;
+        sv = key < Lk ? sv : -1e30f;
+        s_acc[kb][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s_acc[kb][r] - m_new);
+        s_acc[kb][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+
+    // ---- O^T += V^T P^T : 4 key-steps x 2 d-tiles ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float pf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = s_acc[s >> 1][8 * (s & 1) + j];
+      const uint4 pp = pack8<T>(pf);
+      const typename T::vec8 pfrag = __builtin_bit_cast(typename T::vec8, pp);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u16* vrow = &Vs[(t * 32 + lq) * V_LD + 16 * s + 4 * hi];
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+        const uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
+      }
+    }
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l ----
+  if (q_ok) {
+    const float inv = 1.0f / l_run;
+    u16* op = O + (long long)b * o_bs + (long long)q_row * ldo + h * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16 hv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = T::from_f32(o_acc[t][4 * g + e] * inv);
+        uint2 pk;
+        pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+        pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+        *reinterpret_cast<uint2*>(op + t * 32 + 8 * g + 4 * hi) = pk;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, long long ldq, const void* K,
+                              long long k_bstride, long long ldk, const void* Vt, long long vt_bstride,
+                              long long ldvt, void* O, long long o_bstride, long long ldo, int B, int H, int Lq,
+                              int Lk, float scale, void* stream) {
+  DBIR_CHECK_ARG(Q && K && Vt && O, "dbir_attention: null pointer");
+  DBIR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "dbir_attention: bad sizes");
+  DBIR_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && q_bstride % 8 == 0 &&
+                     k_bstride % 8 == 0 && vt_bstride % 8 == 0 && o_bstride % 4 == 0,
+                 "dbir_attention: strides must keep 16-byte (Q,K,Vt) / 8-byte (O) alignment");
+  DBIR_CHECK_ARG(ldvt >= ((Lk + 7) / 8) * 8, "dbir_attention: ldvt %lld too small for Lk %d", ldvt, Lk);
+  DBIR_CHECK_ARG((long long)B * H <= 65535, "dbir_attention: B*H too large for gridDim.y");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(cdiv(Lq, 128), B * H);
+  const float sl2 = scale * 1.4426950408889634f;
+  if (dtype == DBIR_F16)
+    hipLaunchKernelGGL((attn_kernel<F16>), grid, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
+                       k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
+  else if (dtype == DBIR_BF16)
+    hipLaunchKernelGGL((attn_kernel<BF16>), grid, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
+                       k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
+  else {
+    dbir_set_error("dbir_attention: bad dtype %d", dtype);
+    return DBIR_ERR_ARG;
+  }
+  DBIR_CHECK_LAUNCH("dbir_attention");
+  return DBIR_OK;
+}

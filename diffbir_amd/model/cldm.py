@@ -1,0 +1,99 @@
+"""ControlLDM — the stage-2 network object the samplers call (reference cldm.py:20-210), engine-backed.
+
+Keeps the reference surface: ``forward(x_noisy, t, cond)``, ``prepare_condition``,
+``vae_encode``, ``vae_decode``, ``cast_dtype``, ``load_pretrained_sd``, ``load_controlnet_from_ckpt``,
+``control_scales``, ``eval()``, ``to()``; samplers may re-bind ``model.forward`` (tiling).
+"""
+from typing import Dict, List, Set, Tuple
+
+import torch
+
+from .base import NativeModule
+from .clip import FrozenOpenCLIPEmbedder
+from .unet import ControlledUnetModel, ControlNet
+from .vae import AutoencoderKL
+
+T = torch.Tensor
+
+
+class ControlLDM:
+    def __init__(self, unet_cfg, vae_cfg, clip_cfg, controlnet_cfg, latent_scale_factor):
+        self.unet = ControlledUnetModel(**unet_cfg)
+        self.vae = AutoencoderKL(**vae_cfg)
+        self.clip = FrozenOpenCLIPEmbedder(**clip_cfg)
+        self.controlnet = ControlNet(**controlnet_cfg)
+        self.scale_factor = latent_scale_factor
+        self.control_scales = [1.0] * 13
+        self._mods = [self.unet, self.vae, self.clip, self.controlnet]
+
+    # ---- weights ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def load_pretrained_sd(self, sd: Dict[str, T]) -> Tuple[Set[str], Set[str]]:
+        """reference cldm.py:34-62: pick `model.diffusion_model.* / first_stage_model.* / cond_stage_model.*`."""
+        module_map = {"unet": "model.diffusion_model", "vae": "first_stage_model", "clip": "cond_stage_model"}
+        used, missing = set(), set()
+        for name, module in (("unet", self.unet), ("vae", self.vae), ("clip", self.clip)):
+            init = {}
+            for key, (_, kind) in module._spec.items():
+                if kind == "buf":
+                    continue
+                tk = f"{module_map[name]}.{key}"
+                if tk not in sd:
+                    missing.add(tk)
+                    continue
+                init[key] = sd[tk]
+                used.add(tk)
+            module.load_state_dict(init, strict=False)
+        return set(sd.keys()) - used, missing
+
+    @torch.no_grad()
+    def load_controlnet_from_ckpt(self, sd: Dict[str, T]) -> None:
+        self.controlnet.load_state_dict(sd, strict=True)
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, dtype=None):
+        for m in self._mods:
+            m.to(device, dtype) if dtype is not None else m.to(device)
+        return self
+
+    def cast_dtype(self, dtype: torch.dtype) -> "ControlLDM":
+        """reference cldm.py:174-210 casts UNet/ControlNet bodies; here it selects the MFMA compute dtype of the
+        whole engine (VAE included: under the reference's autocast its convs run in the same 16-bit type)."""
+        for m in (self.unet, self.controlnet, self.vae):
+            m.set_dtype(dtype)
+        self.unet.dtype = self.controlnet.dtype = dtype
+        return self
+
+    # ---- VAE / conditioning ---------------------------------------------------------------------
+    def vae_encode(self, image: T, sample: bool = True, tiled: bool = False, tile_size: int = -1) -> T:
+        if tiled:
+            raise NotImplementedError("tiled VAE (VAEHook) is out of scope of this engine: 288 GB HBM3E holds the "
+                                      "untiled activations; see DESIGN.md")
+        if sample:
+            raise NotImplementedError("posterior sampling is a training-only path; inference uses sample=False")
+        return self.vae.encode_mode(image, self.scale_factor)
+
+    def vae_decode(self, z: T, tiled: bool = False, tile_size: int = -1) -> T:
+        if tiled:
+            raise NotImplementedError("tiled VAE (VAEHook) is out of scope of this engine; see DESIGN.md")
+        return self.vae.decode(z, in_scale=1.0 / self.scale_factor)
+
+    def prepare_condition(self, cond_img: T, txt: List[str], tiled: bool = False, tile_size: int = -1) -> Dict[str, T]:
+        """reference cldm.py:143-158: c_img = mode(encoder(img*2-1)) * scale_factor (the `*2-1` is fused into the
+        layout-conversion kernel)."""
+        if tiled:
+            raise NotImplementedError("tiled VAE (VAEHook) is out of scope of this engine; see DESIGN.md")
+        return dict(c_txt=self.clip.encode(txt),
+                    c_img=self.vae.encode_mode(cond_img, self.scale_factor, in_scale=2.0, in_shift=-1.0))
+
+    # ---- network evaluation ---------------------------------------------------------------------
+    def forward(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
+        """reference cldm.py:160-172. x f32 [B,4,h,w], t [B] (int or fractional), cond {c_txt, c_img} -> f32."""
+        c_txt, c_img = cond["c_txt"], cond["c_img"]
+        control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales)
+        return self.unet(x_noisy, t, c_txt, control, only_mid_control=False)
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)

@@ -1,0 +1,300 @@
+"""SD-2.1 UNet and IRControlNet forward passes orchestrated over the HIP kernels (diffbir_amd.ops).
+
+What is computed is exactly reference unet.py:203-223 (ResBlock), attention.py:265-274 / 334-353
+(BasicTransformerBlock / SpatialTransformer, linear projections), controlnet.py:18-47 and 314-328 — but the
+graph is re-expressed for the engine:
+
+  * activations are NHWC 16-bit; every conv / linear is one fused MFMA GEMM launch (bias, time-embedding add,
+    residual, GEGLU, control scale in the epilogue);
+  * torch.cat of the decoder (controlnet.py:41-43) never happens: the producer of `h` writes into the left part
+    of a concat buffer and `hs.pop() + control.pop()` is written into its right part;
+  * to_q/to_k are one GEMM, to_v is emitted transposed for the flash-attention kernel, cross-attention K/V of
+    the (constant) text context are computed once per prompt and cached;
+  * all per-ResBlock `emb_layers` (SiLU -> Linear, unet.py:166-172,212) are evaluated as ONE GEMM per network
+    evaluation, its column slices feed the conv epilogues.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import ops
+from .base import NativeModule
+from .specs import UNetPlan, controlnet_spec, unet_spec
+
+T = torch.Tensor
+
+
+class _Res:
+    __slots__ = ("gn1", "conv1", "gn2", "conv2", "skip", "emb_slice", "cout")
+
+
+class _Attn:
+    __slots__ = ("gn", "proj_in", "ln1", "qk1", "v1", "out1", "ln2", "q2", "k2", "v2", "out2", "ln3", "ff1", "ff2",
+                 "proj_out", "ch", "heads", "ctx_idx")
+
+
+class _DiffusionNet(NativeModule):
+    """Shared machinery of UNet and ControlNet (same encoder)."""
+
+    def __init__(self, cfg: dict, spec, hint_channels: int = 0):
+        super().__init__(spec)
+        self.cfg = dict(cfg)
+        self.plan = UNetPlan(cfg, hint_channels=hint_channels)
+        self.dtype = torch.float32  # reference attribute (cast_dtype sets it); engine dtype is self._dtype
+        self._ctx_cache: Dict[tuple, list] = {}
+
+    # ------------------------------------------------------------------ packing
+    def _pk_norm(self, p):
+        return (self._f32(p + ".weight"), self._f32(p + ".bias"))
+
+    def _pk_lin(self, p, bias=True, **kw):
+        return ops.pack_linear(self._w(p + ".weight"), self._w(p + ".bias") if bias else None, self._dtype,
+                               self._device, **kw)
+
+    def _pk_conv(self, p, **kw):
+        return ops.pack_conv3x3(self._w(p + ".weight"), self._w(p + ".bias"), self._dtype, self._device, **kw)
+
+    def _pack_res(self, p: str, cin: int, cout: int) -> _Res:
+        r = _Res()
+        r.gn1, r.conv1 = self._pk_norm(p + ".in_layers.0"), self._pk_conv(p + ".in_layers.2")
+        r.gn2, r.conv2 = self._pk_norm(p + ".out_layers.0"), self._pk_conv(p + ".out_layers.3")
+        r.skip = self._pk_lin(p + ".skip_connection") if cin != cout else None
+        r.cout = cout
+        self._emb_w.append(self._w(p + ".emb_layers.1.weight"))
+        self._emb_b.append(self._w(p + ".emb_layers.1.bias"))
+        r.emb_slice = (self._emb_off, self._emb_off + cout)
+        self._emb_off += cout
+        return r
+
+    def _pack_attn(self, p: str, ch: int) -> _Attn:
+        a = _Attn()
+        a.ch, a.heads = ch, ch // self.plan.head_dim
+        assert self.plan.head_dim == 64 and self.plan.depth == 1, "engine supports head_dim 64, transformer_depth 1"
+        a.gn = self._pk_norm(p + ".norm")
+        a.proj_in, a.proj_out = self._pk_lin(p + ".proj_in"), self._pk_lin(p + ".proj_out")
+        q = p + ".transformer_blocks.0"
+        a.ln1, a.ln2, a.ln3 = (self._pk_norm(f"{q}.norm{i}") for i in (1, 2, 3))
+        wqk = torch.cat([self._w(f"{q}.attn1.to_q.weight"), self._w(f"{q}.attn1.to_k.weight")], dim=0)
+        a.qk1 = ops.pack_linear(wqk, None, self._dtype, self._device)
+        a.v1 = self._pk_lin(f"{q}.attn1.to_v", bias=False)
+        a.out1 = self._pk_lin(f"{q}.attn1.to_out.0")
+        a.q2 = self._pk_lin(f"{q}.attn2.to_q", bias=False)
+        a.k2 = self._pk_lin(f"{q}.attn2.to_k", bias=False)
+        a.v2 = self._pk_lin(f"{q}.attn2.to_v", bias=False)
+        a.out2 = self._pk_lin(f"{q}.attn2.to_out.0")
+        a.ff1 = ops.pack_geglu(self._w(f"{q}.ff.net.0.proj.weight"), self._w(f"{q}.ff.net.0.proj.bias"), self._dtype,
+                               self._device)
+        a.ff2 = self._pk_lin(f"{q}.ff.net.2")
+        a.ctx_idx = len(self._attn_layers)
+        self._attn_layers.append(a)
+        return a
+
+    def _pack_encoder(self):
+        self._emb_w, self._emb_b, self._emb_off = [], [], 0
+        self._attn_layers: List[_Attn] = []
+        self.te0 = self._pk_lin("time_embed.0")
+        self.te2 = self._pk_lin("time_embed.2")
+        self.enc = []
+        for i, b in enumerate(self.plan.input):
+            p = f"input_blocks.{i}"
+            if b["kind"] == "conv_in":
+                self.enc.append(("conv_in", self._pk_conv(p + ".0", cin_pad_to=8)))
+            elif b["kind"] == "res":
+                res = self._pack_res(p + ".0", b["cin"], b["cout"])
+                att = self._pack_attn(p + ".1", b["cout"]) if b["attn"] else None
+                self.enc.append(("res", res, att))
+            else:
+                self.enc.append(("down", self._pk_conv(p + ".0.op")))
+        c = self.plan.mid_ch
+        self.mid = (self._pack_res("middle_block.0", c, c), self._pack_attn("middle_block.1", c),
+                    self._pack_res("middle_block.2", c, c))
+
+    def _finish_emb(self):
+        w = torch.cat(self._emb_w, dim=0)
+        b = torch.cat(self._emb_b, dim=0)
+        self.emb_all = ops.pack_linear(w, b, self._dtype, self._device)
+        del self._emb_w, self._emb_b
+        self._ctx_cache.clear()
+
+    # ------------------------------------------------------------------ forward pieces
+    def _time_emb(self, t: T) -> T:
+        """[B] -> [B, sum(Cout)] 16-bit: all ResBlock embedding projections of this evaluation."""
+        te = ops.timestep_embedding(t, self.plan.mc, self._dtype)
+        e = ops.linear(te, self.te0, act=ops.ACT_SILU)
+        e = ops.linear(e, self.te2, act=ops.ACT_SILU)  # = SiLU(emb): emb itself is only consumed through SiLU
+        return ops.linear(e, self.emb_all)
+
+    def _res(self, r: _Res, x: T, emb_all: T, out: Optional[T] = None) -> T:
+        h = ops.groupnorm(x, r.gn1[0], r.gn1[1], 1e-5, True)
+        h = ops.conv3x3(h, r.conv1, rowvec=emb_all[:, r.emb_slice[0]:r.emb_slice[1]])
+        h = ops.groupnorm(h, r.gn2[0], r.gn2[1], 1e-5, True)
+        skip = x if r.skip is None else ops.linear(x, r.skip)
+        return ops.conv3x3(h, r.conv2, residual=skip, out=out)
+
+    def context_kv(self, c_txt: T) -> list:
+        """Cross-attention K and V^T of every transformer layer for a text context [B, 77, ctx_dim] (cached:
+        c_txt is constant over all sampling steps)."""
+        self._ensure_packed()
+        key = (c_txt.data_ptr(), tuple(c_txt.shape), c_txt._version, str(self._dtype))
+        hit = self._ctx_cache.get(key)
+        if hit is not None:
+            return hit
+        B, L, D = c_txt.shape
+        c = c_txt.to(self._dtype).contiguous().reshape(B * L, D)
+        Lp = (L + 7) // 8 * 8
+        kv = []
+        for a in self._attn_layers:
+            k = ops.linear(c, a.k2).reshape(B, L, a.ch)
+            vt = torch.zeros((B, a.ch, Lp), dtype=self._dtype, device=c.device)
+            ops.linear_t(c, a.v2, L, vt)
+            kv.append((k, vt))
+        if len(self._ctx_cache) > 64:
+            self._ctx_cache.clear()
+        self._ctx_cache[key] = kv
+        # keep c_txt alive so its data_ptr cannot be recycled while the entry exists
+        kv.append(c_txt)
+        return kv
+
+    def _attn(self, a: _Attn, x: T, ctx_kv: list, out: Optional[T] = None) -> T:
+        B, H, W, C = x.shape
+        L = H * W
+        scale = self.plan.head_dim ** -0.5
+        hn = ops.groupnorm(x, a.gn[0], a.gn[1], 1e-6, False)
+        h = ops.linear(hn.reshape(B * L, C), a.proj_in)
+        # self attention
+        n = ops.layernorm(h, a.ln1[0], a.ln1[1])
+        qk = ops.linear(n, a.qk1).reshape(B, L, 2 * C)
+        vt = torch.empty((B, C, (L + 7) // 8 * 8), dtype=x.dtype, device=x.device)
+        ops.linear_t(n, a.v1, L, vt)
+        o = torch.empty((B, L, C), dtype=x.dtype, device=x.device)
+        ops.attention(qk[..., :C], qk[..., C:], vt, o, a.heads, L, scale)
+        h = ops.linear(o.reshape(B * L, C), a.out1, residual=h)
+        # cross attention (K/V precomputed)
+        n = ops.layernorm(h, a.ln2[0], a.ln2[1])
+        q = ops.linear(n, a.q2).reshape(B, L, C)
+        k_ctx, vt_ctx = ctx_kv[a.ctx_idx]
+        ops.attention(q, k_ctx, vt_ctx, o, a.heads, k_ctx.shape[1], scale)
+        h = ops.linear(o.reshape(B * L, C), a.out2, residual=h)
+        # GEGLU feed-forward
+        n = ops.layernorm(h, a.ln3[0], a.ln3[1])
+        g = ops.linear(n, a.ff1)
+        h = ops.linear(g, a.ff2, residual=h)
+        if out is None:
+            out = torch.empty_like(x)
+        ops.linear(h, a.proj_out, residual=x, out=out)
+        return out
+
+    def _run_block(self, res: _Res, att: Optional[_Attn], h: T, emb_all: T, ctx_kv, out: Optional[T] = None) -> T:
+        if att is None:
+            return self._res(res, h, emb_all, out=out)
+        h = self._res(res, h, emb_all)
+        return self._attn(att, h, ctx_kv, out=out)
+
+    def _encode(self, h: T, emb_all: T, ctx_kv) -> Tuple[List[T], T]:
+        hs = []
+        for blk in self.enc:
+            if blk[0] == "conv_in":
+                h = ops.conv3x3(h, blk[1])
+            elif blk[0] == "res":
+                h = self._run_block(blk[1], blk[2], h, emb_all, ctx_kv)
+            else:
+                h = ops.conv3x3(h, blk[1], stride=2, pad=1)
+            hs.append(h)
+        h = self._res(self.mid[0], h, emb_all)
+        h = self._attn(self.mid[1], h, ctx_kv)
+        h = self._res(self.mid[2], h, emb_all)
+        return hs, h
+
+
+class ControlledUnetModel(_DiffusionNet):
+    """reference controlnet.py:16-47 (UNetModel unet.py:361-685 with control injection)."""
+
+    def __init__(self, **cfg):
+        super().__init__(cfg, unet_spec(cfg))
+
+    def _pack(self):
+        self._pack_encoder()
+        self.dec = []
+        for i, b in enumerate(self.plan.output):
+            p = f"output_blocks.{i}"
+            res = self._pack_res(p + ".0", b["cin"], b["cout"])
+            att = self._pack_attn(p + ".1", b["cout"]) if b["attn"] else None
+            up = self._pk_conv(f"{p}.{2 if b['attn'] else 1}.conv") if b["up"] else None
+            self.dec.append((res, att, up, b))
+        self.out_gn = self._pk_norm("out.0")
+        self.out_conv = self._pk_conv("out.2")
+        self._finish_emb()
+
+    def forward(self, x: T, timesteps: T, context: T, control: Optional[List[T]] = None,
+                only_mid_control: bool = False, **_) -> T:
+        """x: f32 NCHW [B,4,h,w]; control: list of 13 NHWC 16-bit tensors (already scaled) or None -> f32 NCHW."""
+        self._ensure_packed()
+        ctx_kv = self.context_kv(context)
+        emb_all = self._time_emb(timesteps)
+        h = ops.nchw_to_nhwc(x.float().contiguous(), None, 8, self._dtype)
+        hs, h = self._encode(h, emb_all, ctx_kv)
+        control = list(control) if control is not None else None
+        B = h.shape[0]
+
+        def cat_buf(blk, hh, ww):
+            return torch.empty((B, hh, ww, blk["cin"]), dtype=self._dtype, device=h.device)
+
+        # middle output (+ control) goes straight into the left part of the first concat buffer
+        b0 = self.plan.output[0]
+        buf = cat_buf(b0, h.shape[1], h.shape[2])
+        left = buf[..., : b0["cin"] - b0["skip"]]
+        if control is not None:
+            ops.add_scaled(h, control.pop(), 1.0, out=left)
+        else:
+            left.copy_(h)
+        for i, (res, att, up, b) in enumerate(self.dec):
+            skip = hs.pop()
+            right = buf[..., b["cin"] - b["skip"]:]
+            if control is not None and not only_mid_control:
+                ops.add_scaled(skip, control.pop(), 1.0, out=right)
+            else:
+                right.copy_(skip)
+            last = i == len(self.dec) - 1
+            nxt = None if last else self.plan.output[i + 1]
+            hh, ww = buf.shape[1], buf.shape[2]
+            if up is not None:
+                hh, ww = 2 * hh, 2 * ww
+            nbuf = None if last else cat_buf(nxt, hh, ww)
+            target = None if last else nbuf[..., : nxt["cin"] - nxt["skip"]]
+            if up is None:
+                h = self._run_block(res, att, buf, emb_all, ctx_kv, out=target)
+            else:
+                h = self._run_block(res, att, buf, emb_all, ctx_kv)
+                h = ops.conv3x3(h, up, upsample=True, out=target)
+            buf = nbuf
+        h = ops.groupnorm(h, self.out_gn[0], self.out_gn[1], 1e-5, True)
+        o = ops.conv3x3(h, self.out_conv, out_f32=True)
+        return ops.nhwc_to_nchw(o, self.plan.out_ch)
+
+    __call__ = forward
+
+
+class ControlNet(_DiffusionNet):
+    """reference controlnet.py:50-328."""
+
+    def __init__(self, **cfg):
+        super().__init__(cfg, controlnet_spec(cfg), hint_channels=cfg["hint_channels"])
+
+    def _pack(self):
+        self._pack_encoder()
+        self.zero = [self._pk_lin(f"zero_convs.{i}.0") for i in range(len(self.plan.input))]
+        self.zero.append(self._pk_lin("middle_block_out.0"))
+        self._finish_emb()
+
+    def forward(self, x: T, hint: T, timesteps: T, context: T, scales: Optional[List[float]] = None, **_) -> List[T]:
+        """-> 13 control tensors (NHWC 16-bit), multiplied by `scales` (cldm.py:164) in the zero-conv epilogue."""
+        self._ensure_packed()
+        ctx_kv = self.context_kv(context)
+        emb_all = self._time_emb(timesteps)
+        h = ops.nchw_to_nhwc(x.float().contiguous(), hint.float().contiguous(), 8, self._dtype)
+        hs, mid = self._encode(h, emb_all, ctx_kv)
+        feats = hs + [mid]
+        scales = scales if scales is not None else [1.0] * len(feats)
+        return [ops.linear(f, z, out_scale=float(s)) for f, z, s in zip(feats, self.zero, scales)]
+
+    __call__ = forward

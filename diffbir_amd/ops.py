@@ -1,0 +1,446 @@
+"""Thin tensor-level wrappers over the C ABI (include/dbir.h).
+
+PyTorch is plumbing only here: it owns device memory and the current HIP stream; every function below
+validates shapes/strides, then enqueues hand-written gfx950 kernels from libdbir_hip.so on
+`torch.cuda.current_stream()`.  There is no eager / CPU fallback: calling any op without the built library
+or with non-GPU tensors raises.
+
+Conventions
+  * activations are 16-bit (`torch.float16` / `torch.bfloat16`) channels-last: 4-D `[B, H, W, C]` or 2-D `[M, C]`,
+    unit stride in the last dim; the row stride (`ld`) may exceed C (views into wider buffers — this is how
+    torch.cat of the reference (controlnet.py:41-43) is replaced by producers writing into one buffer).
+  * weights are pre-packed once (`pack_*`) into the `[N_pad, K_pad]` K-contiguous layout the MFMA kernel reads.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import native
+from .native import (ACT_GEGLU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_SILU, MODE_CONV3X3, MODE_LINEAR,  # noqa: F401
+                     GemmDesc)
+
+T = torch.Tensor
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _dt(t: T) -> int:
+    if t.dtype == torch.float16:
+        return native.F16
+    if t.dtype == torch.bfloat16:
+        return native.BF16
+    raise TypeError(f"expected a 16-bit tensor, got {t.dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise native.NativeError("diffbir_amd ops need GPU tensors (no CPU fallback in the product path)")
+
+
+def _ld(t: T) -> int:
+    """Row stride (elements) of a channels-last activation whose leading dims are dense over that stride."""
+    assert t.stride(-1) == 1, "last dim must be unit-stride"
+    if t.dim() == 1:
+        return t.shape[0]
+    ld = t.stride(-2)
+    exp = ld
+    for d in range(t.dim() - 2, 0, -1):
+        exp *= t.shape[d]
+        assert t.stride(d - 1) == exp or t.shape[d - 1] == 1, f"leading dims not dense: {t.shape} {t.stride()}"
+    return ld
+
+
+def _rows(t: T) -> int:
+    n = 1
+    for s in t.shape[:-1]:
+        n *= s
+    return n
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------ packing
+@dataclass
+class PackedWeight:
+    w: T                      # [Wrows, Kpad] 16-bit, K-contiguous
+    bias: Optional[T]         # f32 [N] (packed column order) or None
+    N: int                    # packed columns (== 2*N_out for GEGLU)
+    K: int                    # logical K
+    Kpad: int
+    n_out: int                # columns actually written
+    cin: int = 0              # conv3x3: (padded) input channels
+    geglu: bool = False
+
+
+def _finish_pack(w2d: T, bias: Optional[T], dtype, device, n_out=None, cin=0, geglu=False) -> PackedWeight:
+    N, K = w2d.shape
+    Kpad = _rup(K, 64)
+    Wrows = _rup(N, 128)
+    buf = torch.zeros((Wrows, Kpad), dtype=dtype, device=device)
+    buf[:N, :K] = w2d.to(device=device, dtype=dtype)
+    b = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+    return PackedWeight(buf, b, N, K, Kpad, n_out if n_out is not None else N, cin, geglu)
+
+
+def pack_linear(w: T, bias: Optional[T], dtype, device, k_pad_to: int = 8, n_pad_to: int = 1) -> PackedWeight:
+    """nn.Linear / 1x1-conv weight [N, K(,1,1)] -> packed. K is zero-padded to a multiple of `k_pad_to`
+    (activations with padded channel counts, e.g. SwinIR 180 -> 192) and N to `n_pad_to` (extra zero columns)."""
+    w = w.reshape(w.shape[0], -1).float()
+    N, K = w.shape
+    Kp, Np = _rup(K, k_pad_to), _rup(N, n_pad_to)
+    if Kp != K or Np != N:
+        w2 = torch.zeros((Np, Kp), dtype=torch.float32)
+        w2[:N, :K] = w
+        w = w2
+        if bias is not None:
+            b2 = torch.zeros(Np, dtype=torch.float32)
+            b2[:N] = bias.float()
+            bias = b2
+    return _finish_pack(w, bias, dtype, device)
+
+
+def pack_geglu(w: T, bias: T, dtype, device) -> PackedWeight:
+    """GEGLU projection [2*Nh, K] (first half values, second half gates; attention.py:24-26) -> rows interleaved in
+    blocks of 32 (value block, gate block) so a wave's two 32-column MFMA tiles hold matching value/gate columns."""
+    w = w.float()
+    N2, K = w.shape
+    nh = N2 // 2
+    assert nh % 32 == 0, "GEGLU half width must be a multiple of 32"
+    val, gate = w[:nh].reshape(nh // 32, 32, K), w[nh:].reshape(nh // 32, 32, K)
+    wi = torch.stack([val, gate], dim=1).reshape(N2, K)
+    bv, bg = bias.float()[:nh].reshape(nh // 32, 32), bias.float()[nh:].reshape(nh // 32, 32)
+    bi = torch.stack([bv, bg], dim=1).reshape(N2)
+    return _finish_pack(wi, bi, dtype, device, n_out=nh, geglu=True)
+
+
+def pack_conv3x3(w: T, bias: Optional[T], dtype, device, cin_pad_to: int = 8, n_pad_to: int = 1) -> PackedWeight:
+    """Conv2d weight [N, Cin, 3, 3] -> [N, (ky, kx, c)] with Cin zero-padded to a multiple of `cin_pad_to`."""
+    w = w.float()
+    N, Cin = w.shape[:2]
+    Cp, Np = _rup(Cin, cin_pad_to), _rup(N, n_pad_to)
+    w2 = torch.zeros((Np, 3, 3, Cp), dtype=torch.float32)
+    w2[:N, :, :, :Cin] = w.permute(0, 2, 3, 1)
+    if bias is not None and Np != N:
+        b2 = torch.zeros(Np, dtype=torch.float32)
+        b2[:N] = bias.float()
+        bias = b2
+    return _finish_pack(w2.reshape(Np, 9 * Cp), bias, dtype, device, cin=Cp)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+def _gemm_launch(d: GemmDesc, keep):
+    native.check(native.lib().dbir_gemm(ctypes.byref(d), _stream()), "dbir_gemm")
+
+
+def _fill_epilogue(d: GemmDesc, pw: Optional[PackedWeight], act, act_param, out_scale, residual, rowvec,
+                   rows_per_batch, out: T, out_f32: bool):
+    d.bias = pw.bias.data_ptr() if (pw is not None and pw.bias is not None) else None
+    if rowvec is not None:
+        d.rowvec, d.rowvec_ld, d.rows_per_batch = rowvec.data_ptr(), _ld(rowvec), rows_per_batch
+    d.act, d.act_param, d.out_scale = act, act_param, out_scale
+    if residual is not None:
+        d.R, d.ldr = residual.data_ptr(), _ld(residual)
+    d.C, d.ldc, d.out_f32 = out.data_ptr(), _ld(out), int(out_f32)
+    d.batch = 1
+
+
+def linear(x: T, pw: PackedWeight, out: Optional[T] = None, act: int = ACT_NONE, act_param: float = 0.0,
+           out_scale: float = 1.0, residual: Optional[T] = None, rowvec: Optional[T] = None,
+           rows_per_batch: int = 0, out_f32: bool = False, tile: int = 0) -> T:
+    """out[..., :n_out] = epilogue(x[..., :K] @ W^T).  x: [..., K] 16-bit (ld >= K)."""
+    _gpu(x, out, residual, rowvec)
+    M, K = _rows(x), x.shape[-1]
+    assert K == pw.K, f"K mismatch: x has {K}, weight has {pw.K}"
+    if pw.geglu:
+        act = ACT_GEGLU
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (pw.n_out,), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    assert out.shape[-1] == pw.n_out and _rows(out) == M
+    d = GemmDesc()
+    d.mode, d.dtype, d.M, d.N, d.K = MODE_LINEAR, _dt(x), M, pw.N, K
+    d.A, d.lda = x.data_ptr(), _ld(x)
+    d.W, d.Wrows, d.Kpad = pw.w.data_ptr(), pw.w.shape[0], pw.Kpad
+    _fill_epilogue(d, pw, act, act_param, out_scale, residual, rowvec, rows_per_batch, out, out_f32)
+    d.tile = tile
+    _gemm_launch(d, (x, pw, out, residual, rowvec))
+    return out
+
+
+def linear_t(x: T, pw: PackedWeight, L: int, out_t: T) -> T:
+    """Transposed store: out_t[b, n, l] = (x @ W^T)[b*L + l, n] for x: [Bz*L, K]; out_t: [Bz, N, Lpad] 16-bit."""
+    _gpu(x, out_t)
+    M, K = _rows(x), x.shape[-1]
+    assert K == pw.K and M % L == 0 and out_t.dim() == 3 and out_t.shape[1] == pw.n_out
+    assert out_t.stride(2) == 1 and out_t.shape[0] == M // L and out_t.shape[2] >= L
+    d = GemmDesc()
+    d.mode, d.dtype, d.M, d.N, d.K = MODE_LINEAR, _dt(x), M, pw.N, K
+    d.A, d.lda = x.data_ptr(), _ld(x)
+    d.W, d.Wrows, d.Kpad = pw.w.data_ptr(), pw.w.shape[0], pw.Kpad
+    d.bias = pw.bias.data_ptr() if pw.bias is not None else None
+    d.act, d.out_scale = ACT_NONE, 1.0
+    d.C, d.ldc = out_t.data_ptr(), 0
+    d.store_mode, d.trans_L, d.trans_ld, d.trans_bstride = 1, L, out_t.stride(1), out_t.stride(0)
+    d.batch = 1
+    _gemm_launch(d, (x, pw, out_t))
+    return out_t
+
+
+def conv3x3(x: T, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: bool = False,
+            out: Optional[T] = None, act: int = ACT_NONE, act_param: float = 0.0, out_scale: float = 1.0,
+            residual: Optional[T] = None, rowvec: Optional[T] = None, out_f32: bool = False,
+            out_hw: Optional[Tuple[int, int]] = None, tile: int = 0) -> T:
+    """3x3 convolution as implicit GEMM. x: [B, Hi, Wi, Cin] 16-bit DENSE (ld == Cin == pw.cin).
+    `upsample`: nearest x2 fused into the gather. `out_hw` overrides the output extent (VAE asymmetric pad)."""
+    _gpu(x, out, residual, rowvec)
+    B, Hi, Wi, Cin = x.shape
+    assert Cin == pw.cin and _ld(x) == Cin, f"conv3x3 needs dense NHWC input with C == {pw.cin}, got {x.shape} ld {_ld(x)}"
+    Hv, Wv = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
+    if out_hw is None:
+        Ho, Wo = (Hv + 2 * pad - 3) // stride + 1, (Wv + 2 * pad - 3) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    if out is None:
+        out = torch.empty((B, Ho, Wo, pw.n_out), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    assert tuple(out.shape) == (B, Ho, Wo, pw.n_out)
+    d = GemmDesc()
+    d.mode, d.dtype, d.M, d.N, d.K = MODE_CONV3X3, _dt(x), B * Ho * Wo, pw.N, 9 * Cin
+    d.A, d.lda = x.data_ptr(), Cin
+    d.W, d.Wrows, d.Kpad = pw.w.data_ptr(), pw.w.shape[0], pw.Kpad
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo = B, Hi, Wi, Cin, Ho, Wo
+    d.stride, d.pad, d.upsample = stride, pad, int(upsample)
+    _fill_epilogue(d, pw, act, act_param, out_scale, residual, rowvec, Ho * Wo, out, out_f32)
+    d.tile = tile
+    _gemm_launch(d, (x, pw, out, residual, rowvec))
+    return out
+
+
+def bmm_nt(a: T, b: T, out: T, out_scale: float = 1.0) -> T:
+    """Batched out[z] = a[z] @ b[z]^T * out_scale with a: [Z, M, K], b: [Z, N, K], out: [Z, M, N] (16-bit).
+    K % 64 == 0 (zero padded by the caller)."""
+    _gpu(a, b, out)
+    Z, M, K = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == Z and b.shape[2] == K and K % 64 == 0 and tuple(out.shape) == (Z, M, N)
+    assert a.stride(2) == 1 and b.stride(2) == 1 and out.stride(2) == 1
+    d = GemmDesc()
+    d.mode, d.dtype, d.M, d.N, d.K = MODE_LINEAR, _dt(a), M, N, K
+    d.A, d.lda, d.strideA_z = a.data_ptr(), a.stride(1), a.stride(0)
+    # the kernel uses Kpad as the row stride of the W operand: any stride that is a multiple of 64 and >= K works
+    assert b.stride(1) % 64 == 0 and b.stride(1) >= K, "bmm_nt: b row stride must be a multiple of 64 and >= K"
+    d.W, d.Wrows, d.Kpad, d.strideW_z = b.data_ptr(), N, b.stride(1), b.stride(0)
+    d.act, d.out_scale = ACT_NONE, out_scale
+    d.C, d.ldc, d.strideC_z = out.data_ptr(), out.stride(1), out.stride(0)
+    d.batch = Z
+    _gemm_launch(d, (a, b, out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention(q: T, k: T, vt: T, out: T, heads: int, Lk: int, scale: float) -> T:
+    """q: [B, Lq, >=H*64] view, k: [B, Lk, >=H*64] view, vt: [B, H*64, Lkpad] (transposed values), out: [B, Lq, H*64]."""
+    _gpu(q, k, vt, out)
+    B, Lq = q.shape[0], q.shape[1]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1 and out.stride(2) == 1
+    native.check(native.lib().dbir_attention(
+        _dt(q), q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+        vt.data_ptr(), vt.stride(0), vt.stride(1), out.data_ptr(), out.stride(0), out.stride(1),
+        B, heads, Lq, Lk, scale, _stream()), "dbir_attention")
+    return out
+
+
+def window_attention(qkv: T, out: T, bias_table: T, C: int, heads: int, ws: int, shift: int, scale: float) -> T:
+    """qkv: [B, H, W, >=3C]; out: [B, H, W, >=C]; bias_table f32 [(2ws-1)^2, heads]."""
+    _gpu(qkv, out, bias_table)
+    B, H, W = qkv.shape[:3]
+    native.check(native.lib().dbir_window_attention(
+        _dt(qkv), qkv.data_ptr(), _ld(qkv), out.data_ptr(), _ld(out), bias_table.data_ptr(), B, H, W, C, heads, ws,
+        shift, scale, _stream()), "dbir_window_attention")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def groupnorm(x: T, gamma: T, beta: T, eps: float, silu: bool, out: Optional[T] = None, groups: int = 32) -> T:
+    """x: [B, H, W, C] (or [B, HW, C]) 16-bit; gamma/beta f32 [C]."""
+    _gpu(x, gamma, beta, out)
+    B, C = x.shape[0], x.shape[-1]
+    HW = _rows(x) // B
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    nchunk = native.lib().dbir_groupnorm_nchunk(HW, C)
+    ws = torch.empty(B * (2 * C * nchunk + 2 * C), dtype=torch.float32, device=x.device)
+    native.check(native.lib().dbir_groupnorm(
+        _dt(x), x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), gamma.data_ptr(), beta.data_ptr(), B, HW, C, groups,
+        eps, int(silu), ws.data_ptr(), _stream()), "dbir_groupnorm")
+    return out
+
+
+def layernorm(x: T, gamma: T, beta: T, C: Optional[int] = None, eps: float = 1e-5, out: Optional[T] = None) -> T:
+    """Row LayerNorm over the first C columns of x [..., Cpad]; pad columns of the output are zero."""
+    _gpu(x, gamma, beta, out)
+    Cpad = x.shape[-1]
+    C = Cpad if C is None else C
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    native.check(native.lib().dbir_layernorm(
+        _dt(x), x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), gamma.data_ptr(), beta.data_ptr(), _rows(x), C, Cpad,
+        eps, _stream()), "dbir_layernorm")
+    return out
+
+
+def softmax_rows_(x: T, L: int) -> T:
+    """In-place softmax over the first L columns of every row of x [..., ld]; the rest is zeroed."""
+    _gpu(x)
+    assert x.is_contiguous()
+    native.check(native.lib().dbir_softmax_rows(_dt(x), x.data_ptr(), x.shape[-1], _rows(x), L, _stream()),
+                 "dbir_softmax_rows")
+    return x
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def add_scaled(a: T, b: T, s: float, out: Optional[T] = None) -> T:
+    _gpu(a, b, out)
+    if out is None:
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    native.check(native.lib().dbir_add_scaled(_dt(a), a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), s, out.data_ptr(),
+                                              _ld(out), _rows(a), a.shape[-1], _stream()), "dbir_add_scaled")
+    return out
+
+
+def nchw_to_nhwc(src0: T, src1: Optional[T], cpad: int, dtype, scale: float = 1.0, shift: float = 0.0) -> T:
+    _gpu(src0, src1)
+    assert src0.dtype == torch.float32 and src0.is_contiguous() and (src1 is None or src1.is_contiguous())
+    B, C0, H, W = src0.shape
+    C1 = 0 if src1 is None else src1.shape[1]
+    out = torch.empty((B, H, W, cpad), dtype=dtype, device=src0.device)
+    native.check(native.lib().dbir_nchw_to_nhwc(_dt(out), src0.data_ptr(), C0, None if src1 is None else src1.data_ptr(),
+                                                C1, out.data_ptr(), cpad, B, H, W, scale, shift, _stream()),
+                 "dbir_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(src: T, C: int, scale: float = 1.0, shift: Optional[T] = None) -> T:
+    _gpu(src, shift)
+    B, H, W = src.shape[:3]
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=src.device)
+    f32 = src.dtype == torch.float32
+    native.check(native.lib().dbir_nhwc_to_nchw(native.F16 if f32 else _dt(src), src.data_ptr(), int(f32), _ld(src),
+                                                out.data_ptr(), C, B, H, W, scale,
+                                                None if shift is None else shift.data_ptr(), _stream()),
+                 "dbir_nhwc_to_nchw")
+    return out
+
+
+def pixel_unshuffle(src: T, r: int, cpad: int, mean: T, rng: float, dtype) -> T:
+    _gpu(src, mean)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    B, C, H, W = src.shape
+    out = torch.empty((B, H // r, W // r, cpad), dtype=dtype, device=src.device)
+    native.check(native.lib().dbir_pixel_unshuffle(_dt(out), src.data_ptr(), out.data_ptr(), B, C, H, W, r, cpad,
+                                                   mean.data_ptr(), rng, _stream()), "dbir_pixel_unshuffle")
+    return out
+
+
+def timestep_embedding(t: T, dim: int, dtype, max_period: float = 10000.0) -> T:
+    _gpu(t)
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=dtype, device=t.device)
+    native.check(native.lib().dbir_timestep_embedding(_dt(out), t.data_ptr(), out.data_ptr(), t.shape[0], dim,
+                                                      max_period, _stream()), "dbir_timestep_embedding")
+    return out
+
+
+def lincomb4(x: T, ca: T, y: Optional[T] = None, cb: Optional[T] = None, z: Optional[T] = None,
+             cc: Optional[T] = None, w: Optional[T] = None, cd: Optional[T] = None) -> T:
+    """out = ca[b]*x + cb[b]*y + cc[b]*z + cd[b]*w on f32 tensors [B, ...]; coefficient tensors f32 [B]."""
+    _gpu(x, y, z, w, ca, cb, cc, cd)
+    for t in (x, y, z, w):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    p = lambda t: None if t is None else t.data_ptr()
+    native.check(native.lib().dbir_lincomb4(p(x), p(y), p(z), p(w), p(ca), p(cb), p(cc), p(cd), out.data_ptr(), B,
+                                            x.numel() // B, _stream()), "dbir_lincomb4")
+    return out
+
+
+def spaced_step(x: T, oc: T, ou: Optional[T], noise: T, s: float, k_x: T, k_o: T, c1: T, c2: T, sd: T) -> T:
+    _gpu(x, oc, ou, noise, k_x, k_o, c1, c2, sd)
+    for t in (x, oc, ou, noise):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    native.check(native.lib().dbir_spaced_step(x.data_ptr(), oc.data_ptr(), None if ou is None else ou.data_ptr(),
+                                               noise.data_ptr(), s, k_x.data_ptr(), k_o.data_ptr(), c1.data_ptr(),
+                                               c2.data_ptr(), sd.data_ptr(), out.data_ptr(), B, x.numel() // B,
+                                               _stream()), "dbir_spaced_step")
+    return out
+
+
+def tile_gather(x: T, coords: T, ts: int) -> T:
+    """x f32 [B,C,H,W], coords int32 [T,2] -> tiles f32 [T*B, C, ts, ts] (tile-major)."""
+    _gpu(x, coords)
+    assert x.dtype == torch.float32 and x.is_contiguous() and coords.dtype == torch.int32 and coords.is_contiguous()
+    B, C, H, W = x.shape
+    Tn = coords.shape[0]
+    out = torch.empty((Tn * B, C, ts, ts), dtype=torch.float32, device=x.device)
+    native.check(native.lib().dbir_tile_gather(x.data_ptr(), out.data_ptr(), coords.data_ptr(), Tn, B, C, H, W, ts,
+                                               _stream()), "dbir_tile_gather")
+    return out
+
+
+def tile_accumulate(tiles: T, weights: T, coords: T, B: int, H: int, W: int) -> T:
+    _gpu(tiles, weights, coords)
+    assert tiles.dtype == torch.float32 and tiles.is_contiguous() and weights.dtype == torch.float32
+    Tn = coords.shape[0]
+    C, ts = tiles.shape[1], tiles.shape[2]
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=tiles.device)
+    native.check(native.lib().dbir_tile_accumulate(tiles.data_ptr(), weights.data_ptr(), coords.data_ptr(),
+                                                   out.data_ptr(), Tn, B, C, H, W, ts, _stream()),
+                 "dbir_tile_accumulate")
+    return out
+
+
+def u8_to_f32_nchw(src: T) -> T:
+    _gpu(src)
+    assert src.dtype == torch.uint8 and src.is_contiguous() and src.shape[-1] == 3
+    B, H, W = src.shape[:3]
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
+    native.check(native.lib().dbir_u8_to_f32_nchw(src.data_ptr(), out.data_ptr(), B, H, W, _stream()),
+                 "dbir_u8_to_f32_nchw")
+    return out
+
+
+def wavelet_blur(src: T, radius: int) -> T:
+    _gpu(src)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    H, W = src.shape[-2:]
+    out = torch.empty_like(src)
+    native.check(native.lib().dbir_wavelet_blur(src.data_ptr(), out.data_ptr(), src.numel() // (H * W), H, W, radius,
+                                                _stream()), "dbir_wavelet_blur")
+    return out
+
+
+def colorfix(content: T, content_low: T, style_low: T) -> T:
+    _gpu(content, content_low, style_low)
+    out = torch.empty_like(content)
+    native.check(native.lib().dbir_colorfix(content.data_ptr(), content_low.data_ptr(), style_low.data_ptr(),
+                                            out.data_ptr(), content.numel(), _stream()), "dbir_colorfix")
+    return out
+
+
+def f32_nchw_to_u8_nhwc(src: T) -> T:
+    _gpu(src)
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.shape[1] == 3
+    B, _, H, W = src.shape
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=src.device)
+    native.check(native.lib().dbir_f32_nchw_to_u8_nhwc(src.data_ptr(), out.data_ptr(), B, H, W, _stream()),
+                 "dbir_f32_nchw_to_u8_nhwc")
+    return out

@@ -1,0 +1,102 @@
+"""Host-side helpers mirroring reference diffbir/utils/common.py (names / semantics kept: SURVEY.md §8b)."""
+import importlib
+import os
+from typing import Any, Callable, List, Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+
+T = torch.Tensor
+
+
+def get_obj_from_str(string: str) -> Any:
+    module, cls = string.rsplit(".", 1)
+    if module == "diffbir.model" or module.startswith("diffbir.model."):  # reference YAMLs load unchanged
+        module = "diffbir_amd.model" + module[len("diffbir.model"):]
+    return getattr(importlib.import_module(module), cls)
+
+
+def instantiate_from_config(config: Mapping[str, Any]) -> Any:
+    """reference utils/common.py:23-26 (YAML `target:` / `params:` trees)."""
+    if "target" not in config:
+        raise KeyError("Expected key `target` to instantiate.")
+    return get_obj_from_str(config["target"])(**config.get("params", dict()))
+
+
+def load_model_from_url(url_or_path: str) -> dict:
+    """reference utils/common.py:113-120 minus the download (no network in the target environment): accepts a local
+    file path, unwraps `state_dict` and strips a `module.` prefix."""
+    if not os.path.exists(url_or_path):
+        raise FileNotFoundError(f"{url_or_path}: weights must be present locally (downloads are disabled)")
+    sd = torch.load(url_or_path, map_location="cpu")
+    if "state_dict" in sd:
+        sd = sd["state_dict"]
+    if list(sd.keys())[0].startswith("module"):
+        sd = {k[len("module."):]: v for k, v in sd.items()}
+    return sd
+
+
+def sliding_windows(h: int, w: int, tile_size: int, tile_stride: int) -> List[Tuple[int, int, int, int]]:
+    """reference utils/common.py:123-138: regular grid plus an edge-flush window when not aligned."""
+    his = list(range(0, h - tile_size + 1, tile_stride))
+    if (h - tile_size) % tile_stride != 0:
+        his.append(h - tile_size)
+    wis = list(range(0, w - tile_size + 1, tile_stride))
+    if (w - tile_size) % tile_stride != 0:
+        wis.append(w - tile_size)
+    return [(hi, hi + tile_size, wi, wi + tile_size) for hi in his for wi in wis]
+
+
+def gaussian_weights(tile_width: int, tile_height: int) -> np.ndarray:
+    """reference utils/common.py:142-169 — x midpoint (w-1)/2 but y midpoint h/2 (asymmetric; reproduced)."""
+    var = 0.01
+    xm = (tile_width - 1) / 2
+    xs = np.array([np.exp(-(x - xm) * (x - xm) / (tile_width * tile_width) / (2 * var)) / np.sqrt(2 * np.pi * var)
+                   for x in range(tile_width)])
+    ym = tile_height / 2
+    ys = np.array([np.exp(-(y - ym) * (y - ym) / (tile_height * tile_height) / (2 * var)) / np.sqrt(2 * np.pi * var)
+                   for y in range(tile_height)])
+    return np.outer(ys, xs)
+
+
+def make_tiled_fn(fn: Callable, size: int, stride: int, scale_type: str = "up", scale: int = 1,
+                  channel: Optional[int] = None, weight: str = "gaussian", dtype=None, device=None,
+                  progress: bool = True) -> Callable:
+    """reference utils/common.py:172-232 for generic f32 NCHW callables (used for the tiled cleaner).
+    All tiles are gathered by one kernel, `fn` runs per tile (its batch is the image batch, as in the reference) and
+    one kernel does the weighted accumulate + normalise in the reference's tile order.  The diffusion model uses
+    the batched scheduler in utils/tiling.py instead."""
+    if scale != 1 or scale_type != "up":
+        raise NotImplementedError("only scale=1 tiling is on the SwinIR / ControlLDM path")
+
+    def tiled_fn(x: T, *args, **kwargs) -> T:
+        b, c, h, w = x.shape
+        wins = sliding_windows(h, w, size, stride)
+        coords = torch.tensor([[hi, wi] for hi, _, wi, _ in wins], dtype=torch.int32, device=x.device)
+        wt = gaussian_weights(size, size) if weight == "gaussian" else np.ones((size, size))
+        wt = torch.tensor(wt, dtype=torch.float32, device=x.device)
+        tiles = ops.tile_gather(x.float().contiguous(), coords, size)
+        outs = []
+        for t, (hi, he, wi, we) in enumerate(wins):
+            kw = dict(kwargs)
+            if len(args) or len(kwargs):
+                kw.update(dict(hi=hi, hi_end=he, wi=wi, wi_end=we))
+            outs.append(fn(tiles[t * b:(t + 1) * b], *args, **kw).float())
+        return ops.tile_accumulate(torch.cat(outs, dim=0).contiguous(), wt, coords, b, h, w)
+
+    return tiled_fn
+
+
+def wavelet_reconstruction(content_feat: T, style_feat: T, levels: int = 5) -> T:
+    """reference utils/common.py:29-77: high frequencies of `content` + low frequencies of `style`.
+    The reference's running sum  sum_i (img_i - low_i)  telescopes to img_0 - low_last."""
+    def low(img: T) -> T:
+        for i in range(levels):
+            img = ops.wavelet_blur(img, 2 ** i)
+        return img
+
+    c = content_feat.float().contiguous()
+    s = style_feat.float().contiguous()
+    return ops.colorfix(c, low(c), low(s))

@@ -1,0 +1,63 @@
+"""Mixture-of-diffusers tiled-patch scheduler for the diffusion network (reference utils/common.py:172-232 as
+used by spaced_sampler.py:204-219 / dpms_sampler.py:56-71).
+
+The reference evaluates the T tiles of one model evaluation sequentially at batch B.  Tiles are independent
+(GroupNorm / LayerNorm are per sample), so the engine instead
+  1. gathers all windows of the latent with ONE kernel (`dbir_tile_gather`) into a tile-major batch [T*B,4,ts,ts]
+     (the overlapping windows are read once from HBM/L2, not once per tile launch),
+  2. evaluates them as large batches (chunks of `max_batch` samples) -> MFMA tiles stay full at every UNet level,
+  3. blends with ONE kernel (`dbir_tile_accumulate`) that visits tiles in increasing index per output pixel,
+     i.e. the reference's sequential f32 accumulation order, then divides by the summed weights.
+With `shard=(rank, world)` each rank evaluates tiles rank::world and the partial weighted sums are all-reduced
+(SURVEY.md §8e); see diffbir_amd/parallel.py.
+"""
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from .common import gaussian_weights, sliding_windows
+
+T = torch.Tensor
+
+
+class TiledModel:
+    def __init__(self, forward: Callable, tile_size: int, tile_stride: int, max_batch: int = 32):
+        self.forward, self.ts, self.stride, self.max_batch = forward, tile_size, tile_stride, max_batch
+        self._coords: Dict[tuple, T] = {}
+        self._cimg: Dict[tuple, T] = {}
+        self._ctxt: Dict[tuple, T] = {}
+        self._weights: Optional[T] = None
+
+    def _get_coords(self, h, w, device) -> T:
+        key = (h, w, str(device))
+        if key not in self._coords:
+            wins = sliding_windows(h, w, self.ts, self.stride)
+            self._coords[key] = torch.tensor([[hi, wi] for hi, _, wi, _ in wins], dtype=torch.int32, device=device)
+        return self._coords[key]
+
+    def __call__(self, x: T, t: T, cond: Dict[str, T]) -> T:
+        B, C, H, W = x.shape
+        coords = self._get_coords(H, W, x.device)
+        Tn = coords.shape[0]
+        if self._weights is None:
+            self._weights = torch.tensor(gaussian_weights(self.ts, self.ts), dtype=torch.float32, device=x.device)
+        c_img, c_txt = cond["c_img"], cond["c_txt"]
+        kimg = (c_img.data_ptr(), tuple(c_img.shape), c_img._version)
+        if kimg not in self._cimg:  # condition latent is constant over the sampling steps: gather its tiles once
+            self._cimg = {kimg: ops.tile_gather(c_img.float().contiguous(), coords, self.ts)}
+        ktxt = (c_txt.data_ptr(), tuple(c_txt.shape), c_txt._version)
+        if ktxt not in self._ctxt:
+            self._ctxt = {ktxt: c_txt.repeat(Tn, 1, 1).contiguous()}
+        cimg_tiles, ctxt_rep = self._cimg[kimg], self._ctxt[ktxt]
+        tiles = ops.tile_gather(x.float().contiguous(), coords, self.ts)
+        t_rep = t.repeat(Tn)
+        n = Tn * B
+        step = max(B, (self.max_batch // B) * B)
+        outs = []
+        for i in range(0, n, step):
+            j = min(n, i + step)
+            outs.append(self.forward(tiles[i:j], t_rep[i:j], {"c_txt": ctxt_rep[i:j], "c_img": cimg_tiles[i:j]}))
+        eps = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        return ops.tile_accumulate(eps.contiguous(), self._weights, coords, B, H, W)

@@ -1,0 +1,192 @@
+/* dbir.h — C ABI of the MI355X (gfx950) DiffBIR hot-path kernels (libdbir_hip.so).
+ *
+ * The reference (XPixelGroup/DiffBIR) is pure Python on PyTorch: it has no FFI of its own.  Its lowest
+ * boundary on the hot path is the set of torch.nn.functional calls listed below;
+ * each entry point here replaces one of those call families and cites the reference call sites it
+ * stands in for.  All pointers are raw DEVICE pointers owned by the caller (PyTorch allocations), sizes
+ * are plain ints, `stream` is a hipStream_t passed as void*.  Every function only enqueues work on
+ * `stream` (no hidden synchronisation, no allocation) and returns 0 on success or a DBIR_ERR_* code;
+ * `dbir_last_error()` returns a thread-local message.  No torch types cross this boundary.
+ *
+ * Activation layout inside the engine: channels-last (NHWC), 16-bit (f16 or bf16, `dtype`), so that a
+ * feature map is directly the row-major [B*H*W, C] A-operand of an MFMA GEMM.
+ */
+#ifndef DBIR_H
+#define DBIR_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBIR_OK 0
+#define DBIR_ERR_ARG 1
+#define DBIR_ERR_LAUNCH 2
+
+#define DBIR_F16 0
+#define DBIR_BF16 1
+
+/* epilogue activations */
+#define DBIR_ACT_NONE 0
+#define DBIR_ACT_SILU 1
+#define DBIR_ACT_GELU 2   /* exact erf GELU (F.gelu default) */
+#define DBIR_ACT_LRELU 3  /* LeakyReLU(act_param) */
+#define DBIR_ACT_GEGLU 4  /* x * gelu(gate): weights packed value/gate interleaved per 32 columns */
+
+#define DBIR_MODE_LINEAR 0
+#define DBIR_MODE_CONV3X3 1
+
+const char* dbir_last_error(void);
+int dbir_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * dbir_gemm — fused implicit-GEMM on MFMA: C = epilogue(A (*) W^T)
+ * Replaces: F.linear (reference attention.py:22,41,67-73,310,331; unet.py:168,477-479; swinir.py:23-25,
+ * 111,113), F.conv2d 1x1 (unet.py:189; controlnet.py:311; vae.py:93,128-139,569-570) and F.conv2d 3x3
+ * stride 1/2 incl. the preceding nearest-x2 F.interpolate (unet.py:76,99-101,152,178; vae.py:34,46-54,77,84;
+ * swinir.py:471,768,798-808,879-884), plus the elementwise ops the reference performs around them
+ * (bias, `h + emb_out` unet.py:221, residual adds, GEGLU attention.py:24-26, SiLU/GELU/LeakyReLU,
+ * `c * scale` cldm.py:164).
+ *
+ *   mode LINEAR : A is [M, K] 16-bit row-major (row stride lda elements, K % 8 == 0, lda % 8 == 0)
+ *   mode CONV3X3: A is an NHWC 16-bit tensor [B, Hi, Wi, Cin] (Cin % 8 == 0); output pixel (b,oy,ox) is row
+ *                 m = (b*Ho + oy)*Wo + ox; reduction index k = (ky*3+kx)*Cin + c; input coordinate
+ *                 iy = oy*stride - pad + ky (same for x) in the (optionally nearest-x2 upsampled) input.
+ *   W           : 16-bit [Wrows, Kpad] row-major (row n = output column n), Kpad % 64 == 0, zero padded.
+ *   epilogue    : v = acc + bias[n] + rowvec[(m / rows_per_batch) * rowvec_ld + n]; v = act(v);
+ *                 v = v * out_scale + R[m*ldr + n]; store.
+ *   store_mode 0: C[m*ldc + n] (16-bit, or f32 if out_f32)
+ *   store_mode 1: transposed per batch: C[(m / trans_L) * trans_bstride + n * trans_ld + (m % trans_L)]
+ *                 (used to emit V^T for the attention kernel).
+ *   gridDim.z = batch with per-z element strides (strideA_z, strideW_z, strideC_z, strideR_z).
+ */
+typedef struct dbir_gemm_desc {
+  int mode, dtype;
+  int M, N, K;
+  const void* A;
+  long long lda, strideA_z;
+  const void* W;
+  int Wrows, Kpad;
+  long long strideW_z;
+  /* conv geometry */
+  int B, Hi, Wi, Cin, Ho, Wo, stride, pad, upsample;
+  /* epilogue */
+  const float* bias;
+  const void* rowvec; /* 16-bit [*, rowvec_ld] or NULL */
+  int rowvec_ld, rows_per_batch;
+  int act;
+  float act_param, out_scale;
+  const void* R; /* 16-bit residual or NULL */
+  long long ldr, strideR_z;
+  void* C;
+  long long ldc, strideC_z;
+  int out_f32;
+  int store_mode, trans_L;
+  long long trans_ld, trans_bstride;
+  int batch;
+  int tile; /* 0 = auto; 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64 (testing / tuning) */
+} dbir_gemm_desc;
+int dbir_gemm(const dbir_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * dbir_attention — flash-style softmax(Q K^T * scale) V, head_dim 64, no mask.
+ * Replaces F.scaled_dot_product_attention at reference attention.py:206 (UNet/ControlNet self- and
+ * cross-attention; xformers path attention.py:153 is the same math).
+ *   Q : 16-bit, element (b, i, h, d) at Q[b*q_bstride + i*ldq + h*64 + d]
+ *   K : same addressing with k_bstride/ldk over Lk keys
+ *   Vt: TRANSPOSED values: element (b, h, d, j) at Vt[b*vt_bstride + (h*64 + d)*ldvt + j]; ldvt % 8 == 0 and
+ *       columns j in [Lk, ldvt) must be readable (they are masked to zero in-kernel).
+ *   O : element (b, i, h, d) at O[b*o_bstride + i*ldo + h*64 + d]
+ */
+int dbir_attention(int dtype, const void* Q, long long q_bstride, long long ldq, const void* K,
+                   long long k_bstride, long long ldk, const void* Vt, long long vt_bstride, long long ldvt,
+                   void* O, long long o_bstride, long long ldo, int B, int H, int Lq, int Lk, float scale,
+                   void* stream);
+
+/* dbir_window_attention — Swin (shifted-)window MHSA core: per window of ws*ws tokens
+ * softmax(q k^T * scale + rel_pos_bias + shift_mask) v, including the cyclic roll and window
+ * partition / reverse index maps.  Replaces reference swinir.py:126-149 together with 37-66, 222-243, 255-282.
+ *   qkv : 16-bit [B, H, W, ld] with q at cols [0,C), k at [C,2C), v at [2C,3C) (real C = heads*hd)
+ *   out : 16-bit [B, H, W, ldo], cols [0,C) written (token order = image order, roll undone)
+ *   bias_table: f32 [(2ws-1)^2, heads]
+ */
+int dbir_window_attention(int dtype, const void* qkv, long long ld, void* out, long long ldo,
+                          const float* bias_table, int B, int H, int W, int C, int heads, int ws, int shift,
+                          float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Normalisation.  dbir_groupnorm replaces GroupNorm32 (+SiLU) reference util.py:191-193 / unet.py:149-153,
+ * 173-180, nn.GroupNorm(32, C, eps=1e-6) at attention.py:48-51 and vae.py:18-21 (+swish vae.py:13-15).
+ * x,y: NHWC 16-bit [B, HW, C] (row strides ldx/ldy); statistics in f32 over (HW, C/groups) per (b, group).
+ * workspace: f32, at least B * (2*C*nchunk + 2*C) floats where nchunk = dbir_groupnorm_nchunk(HW, C).
+ */
+int dbir_groupnorm_nchunk(int HW, int C);
+int dbir_groupnorm(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                   const float* beta, int B, int HW, int C, int groups, float eps, int silu, float* workspace,
+                   void* stream);
+/* dbir_layernorm: nn.LayerNorm rows (attention.py:255-257; swinir.py:205,211,764), eps 1e-5.
+ * Normalises over the first C columns; columns [C, Cpad) of y are written as zero. */
+int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                   const float* beta, int rows, int C, int Cpad, float eps, void* stream);
+/* dbir_softmax_rows: in-place row softmax over the first L columns of a 16-bit [rows, ld] matrix (f32 math),
+ * columns [L, ld) set to zero.  Used by the single-head d=C VAE attention (vae.py:272). */
+int dbir_softmax_rows(int dtype, void* x, long long ld, long long rows, int L, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout / elementwise. */
+/* out[m, :C] (ldo) = a[m, :C] (lda) + s * b[m, :C] (ldb); 16-bit; C % 8 == 0.
+ * (`hs.pop() + control.pop()` and `h += control.pop()` controlnet.py:37,43; writes straight into the
+ * concat buffer that replaces torch.cat controlnet.py:41-43.) */
+int dbir_add_scaled(int dtype, const void* a, long long lda, const void* b, long long ldb, float s, void* out,
+                    long long ldo, long long M, int C, void* stream);
+/* NCHW f32 sources -> NHWC 16-bit [B,H,W,Cpad]: channels = cat(src0[C0], src1[C1]) * scale + shift, zero
+ * padded to Cpad.  (torch.cat((x, hint)) controlnet.py:317; `.type(self.dtype)` :320; `img*2-1` cldm.py:153.) */
+int dbir_nchw_to_nhwc(int dtype, const float* src0, int C0, const float* src1, int C1, void* dst, int Cpad, int B,
+                      int H, int W, float scale, float shift, void* stream);
+/* NHWC (16-bit or f32 if src_f32) [B,H,W,ld] first C channels -> NCHW f32, y = x*scale + shift[c]. */
+int dbir_nhwc_to_nchw(int dtype, const void* src, int src_f32, long long ld, float* dst, int C, int B, int H,
+                      int W, float scale, const float* shift, void* stream);
+/* SwinIR front end: (x - mean[c]) * range, PixelUnshuffle(r), NCHW f32 -> NHWC 16-bit [B,H/r,W/r,Cpad]
+ * (swinir.py:860-861, 702-705). Output channel = c*r*r + dy*r + dx. */
+int dbir_pixel_unshuffle(int dtype, const float* src, void* dst, int B, int C, int H, int W, int r, int Cpad,
+                         const float* mean, float range, void* stream);
+/* sinusoidal timestep embedding (util.py:128-148): t f32 [B] -> 16-bit [B, dim] = cat(cos, sin). */
+int dbir_timestep_embedding(int dtype, const float* t, void* out, int B, int dim, float max_period, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sampler step math on f32 [B, n] latents (n = C*H*W), coefficients per batch row.
+ * out = ca[b]*x + cb[b]*y + cc[b]*z + cd[b]*w   (any of y,z,w may be NULL)
+ * Covers CFG mixing, x0-from-eps/v, posterior mean + sqrt(var)*noise (spaced_sampler.py:158,175-183) and the
+ * DPM-Solver++ updates (dpm_solver_pytorch.py:451-459, 590-594, 842-849). */
+int dbir_lincomb4(const float* x, const float* y, const float* z, const float* w, const float* ca,
+                  const float* cb, const float* cc, const float* cd, float* out, int B, long long n, void* stream);
+/* Fused spaced-DDPM step (spaced_sampler.py:144-184): model outputs oc/ou (f32 [B,n]), CFG scale s,
+ * x0 = k_x[b]*x - k_o[b]*(ou + s*(oc-ou)); x_prev = c1[b]*x0 + c2[b]*x + sd[b]*noise. ou may be NULL (no CFG). */
+int dbir_spaced_step(const float* x, const float* oc, const float* ou, const float* noise, float s,
+                     const float* k_x, const float* k_o, const float* c1, const float* c2, const float* sd,
+                     float* out, int B, long long n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mixture-of-diffusers tiling (utils/common.py:172-232).
+ * tile_gather: x f32 [B,C,H,W] -> tiles f32 [T*B, C, ts, ts] (tile-major: index t*B + b), coords int32 [T,2]
+ * (hi, wi).  tile_accumulate: out[b,c,y,x] = sum_t tiles[t*B+b,c,y-hi_t,x-wi_t]*w[y-hi_t,x-wi_t] /
+ * sum_t w[...] with tiles visited in increasing t (the reference's sequential order => same f32 rounding). */
+int dbir_tile_gather(const float* x, float* tiles, const int* coords, int T, int B, int C, int H, int W, int ts,
+                     void* stream);
+int dbir_tile_accumulate(const float* tiles, const float* weights, const int* coords, float* out, int T, int B,
+                         int C, int H, int W, int ts, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pre/post image ops (pipeline.py:265-271, 306-320; utils/common.py:29-77). */
+int dbir_u8_to_f32_nchw(const unsigned char* src, float* dst, int B, int H, int W, void* stream);
+/* depthwise 3x3 [1,2,1]x[1,2,1]/16 blur with dilation `radius`, replicate padding; f32 planes [P,H,W]. */
+int dbir_wavelet_blur(const float* src, float* dst, int P, int H, int W, int radius, void* stream);
+/* out = (content - content_low) + style_low on f32 NCHW tensors of n elements (wavelet_reconstruction with the
+ * telescoped sum of common.py:50-62: sum_i (img_i - low_i) = img_0 - low_last). */
+int dbir_colorfix(const float* content, const float* content_low, const float* style_low, float* out,
+                  long long n, void* stream);
+/* dst_u8[b,y,x,c] = (uint8) clamp(src[b,c,y,x] * 255, 0, 255)  (pipeline.py:312-320; truncating cast). */
+int dbir_f32_nchw_to_u8_nhwc(const float* src, unsigned char* dst, int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBIR_H */

@@ -1,0 +1,44 @@
+"""Shared test helpers: build the engine-side models from seeded synthetic weights."""
+import numpy as np
+import torch
+
+from oracle import cases
+from diffbir_amd import configs
+from diffbir_amd.model import ControlLDM, Diffusion, SwinIR
+from diffbir_amd.pipeline import SwinIRPipeline
+
+
+def build_engine(cfg_name: str, diffusion_cfg: str, device, dtype, W=None, raw_dtype=False):
+    """-> (pipeline, cldm, swinir). raw_dtype=True forces `_dtype` without the 16-bit check (CPU emulation in f32)."""
+    cldm_cfg, swin_cfg = cases.get_cfgs(cfg_name)
+    if W is None:
+        W = cases.synth_weights(cldm_cfg, swin_cfg, 0)
+    cldm = ControlLDM(**cldm_cfg)
+    cldm.unet.load_state_dict(W["unet"], strict=True)
+    cldm.controlnet.load_state_dict(W["controlnet"], strict=True)
+    cldm.vae.load_state_dict(W["vae"], strict=True)
+    cldm.clip.load_state_dict(W["clip"], strict=True)
+    swin = SwinIR(**swin_cfg)
+    swin.load_state_dict(W["swinir"], strict=True)
+    mods = [cldm.unet, cldm.controlnet, cldm.vae, swin]
+    for m in mods + [cldm.clip]:
+        m.to(device)
+    for m in mods:
+        if raw_dtype:
+            m._dtype, m._packed = dtype, False
+        else:
+            m.set_dtype(dtype)
+    diff = Diffusion(**configs.get(diffusion_cfg))
+    pipe = SwinIRPipeline(swin, cldm, diff, None, str(device))
+    return pipe, cldm, swin
+
+
+def run_pipe(pipe, lq, steps, sampler, seed, cfg=4.0, tiled=False, tile=512, stride=256, cleaner_tiled=False):
+    pipe.randn = cases.NoiseStream(seed)
+    return pipe.run(lq, steps, 1.0, cleaner_tiled, 512, 256, False, 256, False, 256, tiled, tile, stride,
+                    "", cases.NEG_PROMPT, cfg, "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
+
+
+def rel_err(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item(), (a - b).abs().max().item()

@@ -1,0 +1,65 @@
+"""CPU validation of the host-side orchestration (layouts, weight packing, fusion bookkeeping, samplers, tiling,
+pipeline) with `diffbir_amd.ops` replaced by the PyTorch test double (tests/emu_ops.py) in f32 — compared against
+golden vectors produced by the unmodified reference.  The HIP kernels themselves are checked against the same
+test double in tests/test_kernels_gpu.py (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from tests import emu_ops
+from tests.helpers import build_engine, rel_err, run_pipe
+
+
+@pytest.fixture()
+def engine(monkeypatch):
+    emu_ops.install(monkeypatch)
+    return build_engine("tiny", "DIFFUSION_V21", torch.device("cpu"), torch.float32, raw_dtype=True)
+
+
+@torch.no_grad()
+def test_modules_vs_reference_golden(engine, golden_dir):
+    pipe, cldm, swin = engine
+    gm = np.load(os.path.join(golden_dir, "tiny_modules.npz"))
+    rs = cases.NoiseStream(7)
+    x = torch.tensor(cases.make_lq(11, 2, 128, 128)).float().div(255).permute(0, 3, 1, 2).contiguous()
+    assert rel_err(swin(x), gm["swinir_out"])[0] < 1e-4
+    assert rel_err(cldm.vae.encode_mode(x, 0.18215, 2.0, -1.0), gm["vae_mode"])[0] < 1e-4
+    z = rs((2, 4, 16, 16))
+    assert rel_err(cldm.vae_decode(z), gm["vae_dec"])[0] < 1e-4
+    c_txt = cldm.clip(torch.tensor(gm["tokens"]))
+    assert rel_err(c_txt, gm["c_txt"])[0] < 1e-5
+    xn = rs((2, 4, 16, 16))
+    c_img = rs((2, 4, 16, 16)) * 0.5
+    cldm.control_scales = [0.9] * 13
+    e = cldm(xn, torch.tensor([999, 381]), dict(c_txt=c_txt, c_img=c_img))
+    assert rel_err(e, gm["eps_int_t"])[0] < 2e-4
+    e = cldm(xn, torch.tensor([949.0365, 49.95]), dict(c_txt=c_txt, c_img=c_img))
+    assert rel_err(e, gm["eps_float_t"])[0] < 2e-4
+    ctrl = cldm.controlnet(xn, c_img, torch.tensor([999, 381]), c_txt)
+    assert rel_err(ctrl[0].permute(0, 3, 1, 2), gm["control_0"])[0] < 2e-4
+    assert rel_err(ctrl[12].permute(0, 3, 1, 2), gm["control_12"])[0] < 2e-4
+
+
+CASES = [
+    ("spaced6_v21", "DIFFUSION_V21", (3, 1, 512, 512), 6, "spaced", 231, {}),
+    ("dpm10_v21", "DIFFUSION_V21", (3, 1, 512, 512), 10, "dpm++_m2", 231, {}),
+    ("spaced6_v2", "DIFFUSION_V2", (3, 1, 512, 512), 6, "spaced", 231, {}),
+    ("spaced4_b2_v21", "DIFFUSION_V21", (5, 2, 512, 512), 4, "spaced", 99, {}),
+    ("spaced3_pad_v21", "DIFFUSION_V21", (9, 1, 600, 712), 3, "spaced", 5, {}),
+    ("spaced3_tiled_v21", "DIFFUSION_V21", (9, 1, 600, 712), 3, "spaced", 5, dict(tiled=True)),
+    ("dpm10_tiled_v21", "DIFFUSION_V21", (9, 1, 600, 712), 10, "dpm++_m2", 5, dict(tiled=True)),
+]
+
+
+@pytest.mark.parametrize("name,dcfg,lqspec,steps,sampler,seed,kw", CASES, ids=[c[0] for c in CASES])
+def test_pipeline_vs_reference_golden(monkeypatch, golden_dir, name, dcfg, lqspec, steps, sampler, seed, kw):
+    emu_ops.install(monkeypatch)
+    pipe, cldm, swin = build_engine("tiny", dcfg, torch.device("cpu"), torch.float32, raw_dtype=True)
+    ref = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))[name]
+    out = run_pipe(pipe, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+    assert out.shape == ref.shape and out.dtype == np.uint8
+    psnr = cases.psnr_u8(out, ref)
+    assert psnr > 60.0, psnr
