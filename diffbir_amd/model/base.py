@@ -35,7 +35,7 @@ class NativeModule:
             v = sd[k]
             if tuple(v.shape) != shp:
                 raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {shp}")
-            self._sd[k] = v.detach().to("cpu", torch.float32)
+            self._sd[k] = v.detach()  # kept where it lives (CPU checkpoints stay on CPU); cast when packed
         self._packed = False
         return missing, unexpected
 
@@ -94,3 +94,8 @@ class NativeModule:
 
     def _f32(self, key: str) -> torch.Tensor:
         return self._sd[key].to(self._device, torch.float32).contiguous()
+
+    def release_master(self):
+        """Drop the unpacked checkpoint tensors once packed (frees ~4 bytes/param of host or device memory)."""
+        self._ensure_packed()
+        self._sd = {}

@@ -127,7 +127,7 @@ class FrozenOpenCLIPEmbedder(NativeModule):
         self.layer_idx = {"last": 0, "penultimate": 1}[layer]
 
     def _pack(self):
-        self.P = {k: v.to(self._device) for k, v in self._sd.items()}
+        self.P = {k: v.to(self._device, torch.float32) for k, v in self._sd.items()}
 
     def set_dtype(self, dtype):  # CLIP stays f32 (reference keeps fp32 weights; loop.py:82)
         return self

@@ -97,11 +97,11 @@ def pack_linear(w: T, bias: Optional[T], dtype, device, k_pad_to: int = 8, n_pad
     N, K = w.shape
     Kp, Np = _rup(K, k_pad_to), _rup(N, n_pad_to)
     if Kp != K or Np != N:
-        w2 = torch.zeros((Np, Kp), dtype=torch.float32)
+        w2 = torch.zeros((Np, Kp), dtype=torch.float32, device=w.device)
         w2[:N, :K] = w
         w = w2
         if bias is not None:
-            b2 = torch.zeros(Np, dtype=torch.float32)
+            b2 = torch.zeros(Np, dtype=torch.float32, device=w.device)
             b2[:N] = bias.float()
             bias = b2
     return _finish_pack(w, bias, dtype, device)
@@ -126,18 +126,54 @@ def pack_conv3x3(w: T, bias: Optional[T], dtype, device, cin_pad_to: int = 8, n_
     w = w.float()
     N, Cin = w.shape[:2]
     Cp, Np = _rup(Cin, cin_pad_to), _rup(N, n_pad_to)
-    w2 = torch.zeros((Np, 3, 3, Cp), dtype=torch.float32)
+    w2 = torch.zeros((Np, 3, 3, Cp), dtype=torch.float32, device=w.device)
     w2[:N, :, :, :Cin] = w.permute(0, 2, 3, 1)
     if bias is not None and Np != N:
-        b2 = torch.zeros(Np, dtype=torch.float32)
+        b2 = torch.zeros(Np, dtype=torch.float32, device=w.device)
         b2[:N] = bias.float()
         bias = b2
     return _finish_pack(w2.reshape(Np, 9 * Cp), bias, dtype, device, cin=Cp)
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
+_PROFILE = None  # list of (kind, algorithmic_flops, start_event, end_event) while profiling (bench.py roofline)
+
+
+def start_profile():
+    global _PROFILE
+    _PROFILE = []
+    return _PROFILE
+
+
+def stop_profile():
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    return rec
+
+
+class _Timed:
+    """Brackets ONE kernel launch with HIP events on the current stream when profiling is on (else free)."""
+
+    def __init__(self, kind: str, flops: float):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _PROFILE is not None:
+            self.e1.record()
+            _PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+        return False
+
+
 def _gemm_launch(d: GemmDesc, keep):
-    native.check(native.lib().dbir_gemm(ctypes.byref(d), _stream()), "dbir_gemm")
+    with _Timed("gemm", 2.0 * d.M * (d.N) * d.K * max(d.batch, 1)):
+        native.check(native.lib().dbir_gemm(ctypes.byref(d), _stream()), "dbir_gemm")
 
 
 def _fill_epilogue(d: GemmDesc, pw: Optional[PackedWeight], act, act_param, out_scale, residual, rowvec,
@@ -249,10 +285,11 @@ def attention(q: T, k: T, vt: T, out: T, heads: int, Lk: int, scale: float) -> T
     _gpu(q, k, vt, out)
     B, Lq = q.shape[0], q.shape[1]
     assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1 and out.stride(2) == 1
-    native.check(native.lib().dbir_attention(
-        _dt(q), q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
-        vt.data_ptr(), vt.stride(0), vt.stride(1), out.data_ptr(), out.stride(0), out.stride(1),
-        B, heads, Lq, Lk, scale, _stream()), "dbir_attention")
+    with _Timed("attention", 4.0 * B * heads * Lq * Lk * 64):
+        native.check(native.lib().dbir_attention(
+            _dt(q), q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+            vt.data_ptr(), vt.stride(0), vt.stride(1), out.data_ptr(), out.stride(0), out.stride(1),
+            B, heads, Lq, Lk, scale, _stream()), "dbir_attention")
     return out
 
 

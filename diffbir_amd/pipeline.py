@@ -138,7 +138,10 @@ class Pipeline:
             rescale_cfg: bool, s_churn: float, s_tmin: float, s_tmax: float, s_noise: float, eta: float,
             order: int) -> np.ndarray:
         """reference pipeline.py:235-321."""
-        lq_u8 = torch.as_tensor(np.ascontiguousarray(lq), dtype=torch.uint8).to(self.device)
+        if isinstance(lq, torch.Tensor):  # engine extension: batch already resident in HBM
+            lq_u8 = lq.to(device=self.device, dtype=torch.uint8).contiguous()
+        else:
+            lq_u8 = torch.as_tensor(np.ascontiguousarray(lq), dtype=torch.uint8).to(self.device)
         lq_tensor = ops.u8_to_f32_nchw(lq_u8)
         self.set_output_size(lq_tensor.size())
         cond_img = self.apply_cleaner(lq_tensor, cleaner_tiled, cleaner_tile_size, cleaner_tile_stride)

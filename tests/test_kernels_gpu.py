@@ -1,0 +1,323 @@
+"""-m gpu: every HIP kernel (through the C ABI, via diffbir_amd.ops) against the plain-PyTorch f32 reference of
+the same op (tests/emu_ops.py) on identical seeded inputs.  Tolerances (stated per dtype below) are those of a
+16-bit result with f32 accumulation: the two sides differ only in summation order and the final rounding."""
+import json
+import os
+
+import pytest
+import torch
+
+from tests import emu_ops as emu
+
+pytestmark = pytest.mark.gpu
+
+ops = None
+DEV = None
+REPORT = []
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _setup():
+    global ops, DEV
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from diffbir_amd import native, ops as real_ops
+    native.lib()  # raises loudly if the HIP extension is missing
+    ops = real_ops
+    DEV = torch.device("cuda:0")
+    yield
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "kernel_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+# 16-bit outputs, f32 accumulate: relative-L2 and max-abs (normalised by the reference's max magnitude) bounds
+TOL = {torch.float16: (1.5e-3, 6e-3), torch.bfloat16: (1.0e-2, 4e-2), torch.float32: (2e-4, 1e-3)}
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def check(name, got, ref, dtype, scale=1.0):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    rl2 = ((got - ref).norm() / ref.norm().clamp_min(1e-20)).item()
+    mx = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-20)).item()
+    REPORT.append(dict(name=name, rel_l2=rl2, max_norm=mx, dtype=str(dtype)))
+    t = TOL[dtype]
+    assert rl2 <= t[0] * scale and mx <= t[1] * scale, f"{name}: rel_l2={rl2:.3e} max_norm={mx:.3e} (tol {t}, x{scale})"
+
+
+def rnd(*shape, dtype=torch.float16, s=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * s).to(DEV).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / linear
+LIN_CASES = [
+    # M, N, K, tile
+    (1000, 320, 320, 0), (128, 128, 64, 1), (200, 136, 72, 2), (70, 40, 8, 3), (300, 200, 1024, 4),
+    (4096, 640, 2560, 0), (3, 1280, 320, 0), (154, 1280, 1024, 0), (64, 1280, 5120, 3), (257, 96, 200, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,tile", LIN_CASES)
+def test_linear_plain(M, N, K, tile, dtype):
+    x = rnd(M, K, dtype=dtype)
+    w, b = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    check(f"linear {M}x{N}x{K} t{tile}", ops.linear(x, pw, tile=tile), emu.linear(x, pw), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [emu.ACT_SILU, emu.ACT_GELU, emu.ACT_LRELU])
+def test_linear_epilogue(act, dtype):
+    M, N, K, rpb = 384, 200, 136, 96
+    x_wide = rnd(M, K + 24, dtype=dtype)
+    x = x_wide[:, :K]                                  # strided A (ld > K)
+    w, b = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    res = rnd(M, N + 8, dtype=dtype, seed=3)[:, :N]    # strided residual
+    rv = rnd(M // rpb, N + 16, dtype=dtype, seed=4)[:, 8:8 + N]  # strided, offset row vector
+    out_a = torch.zeros(M, N + 40, dtype=dtype, device=DEV)
+    out_b = torch.zeros(M, N + 40, dtype=dtype, device=DEV)
+    kw = dict(act=act, act_param=0.2, out_scale=0.7, residual=res, rowvec=rv, rows_per_batch=rpb)
+    ops.linear(x, pw, out=out_a[:, 16:16 + N], **kw)
+    emu.linear(x, pw, out=out_b[:, 16:16 + N], **kw)
+    check(f"linear epilogue act{act}", out_a, out_b, dtype)   # also checks nothing outside the view is touched
+    o32 = ops.linear(x, pw, out_f32=True, **kw)
+    assert o32.dtype == torch.float32
+    check(f"linear f32out act{act}", o32, emu.linear(x, pw, out_f32=True, **kw), torch.float32, scale=4.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Nh,K,tile", [(512, 1280, 320, 0), (100, 64, 64, 2), (4096, 2560, 640, 1)])
+def test_linear_geglu(M, Nh, K, tile, dtype):
+    x = rnd(M, K, dtype=dtype)
+    w, b = rnd(2 * Nh, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(2 * Nh, dtype=torch.float32, seed=2)
+    pw = ops.pack_geglu(w.cpu(), b.cpu(), dtype, DEV)
+    got = ops.linear(x, pw, tile=tile)
+    # independent statement of GEGLU on the UNPACKED weights (checks the packing interleave too)
+    h = x.float() @ w.to(dtype).float().t() + b
+    ref = (h[:, :Nh] * torch.nn.functional.gelu(h[:, Nh:])).to(dtype)
+    check(f"geglu {M}x{Nh}x{K}", got, ref, dtype)
+    res = rnd(M, Nh, dtype=dtype, seed=5)
+    check("geglu+res", ops.linear(x, pw, residual=res), emu.linear(x, pw, residual=res), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Bz,L,N,K", [(2, 64, 128, 64), (3, 77, 320, 1024), (2, 100, 64, 72), (2, 1024, 640, 640)])
+def test_linear_transposed(Bz, L, N, K, dtype):
+    x = rnd(Bz * L, K, dtype=dtype)
+    w = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1)
+    pw = ops.pack_linear(w.cpu(), None, dtype, DEV)
+    Lp = (L + 7) // 8 * 8
+    a = torch.zeros(Bz, N, Lp, dtype=dtype, device=DEV)
+    b = torch.zeros(Bz, N, Lp, dtype=dtype, device=DEV)
+    ops.linear_t(x, pw, L, a)
+    emu.linear_t(x, pw, L, b)
+    check(f"linear_t {Bz}x{L}x{N}x{K}", a, b, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bmm_nt(dtype):
+    Z, M, N, K = 3, 200, 136, 128
+    qk = rnd(Z, M, 2 * K, dtype=dtype)                     # q / k views with row stride 2K (VAE attention layout)
+    out = torch.zeros(Z, M, M + 56, dtype=dtype, device=DEV)
+    ref = torch.zeros_like(out)
+    ops.bmm_nt(qk[..., :K], qk[..., K:], out[..., :M], out_scale=0.3)
+    emu.bmm_nt(qk[..., :K], qk[..., K:], ref[..., :M], out_scale=0.3)
+    check("bmm_nt strided", out, ref, dtype)
+    a, b = rnd(Z, M, K, dtype=dtype, seed=1), rnd(Z, N, K, dtype=dtype, seed=2)
+    o1, o2 = torch.empty(Z, M, N, dtype=dtype, device=DEV), torch.empty(Z, M, N, dtype=dtype, device=DEV)
+    check("bmm_nt dense", ops.bmm_nt(a, b, o1), emu.bmm_nt(a, b, o2), dtype)
+
+
+# ------------------------------------------------------------------------------------------------ conv3x3
+CONV_CASES = [
+    # B, H, W, Cin, N, stride, pad, upsample, out_hw, tile
+    (2, 16, 16, 64, 128, 1, 1, False, None, 0), (1, 20, 12, 8, 320, 1, 1, False, None, 0),
+    (2, 16, 16, 64, 64, 2, 1, False, None, 0), (2, 16, 16, 32, 32, 2, 0, False, (8, 8), 0),
+    (2, 8, 8, 128, 128, 1, 1, True, None, 0), (1, 17, 13, 72, 200, 1, 1, False, None, 1),
+    (1, 9, 9, 192, 192, 1, 1, False, None, 3), (2, 8, 8, 1280, 1280, 1, 1, False, None, 0),
+    (1, 64, 64, 320, 320, 1, 1, False, None, 1), (1, 15, 15, 64, 64, 2, 1, False, None, 2),
+    (1, 6, 10, 40, 72, 1, 1, True, None, 4),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,N,stride,pad,ups,ohw,tile", CONV_CASES)
+def test_conv3x3(B, H, W, Cin, N, stride, pad, ups, ohw, tile, dtype):
+    x = rnd(B, H, W, Cin, dtype=dtype)
+    w = rnd(N, Cin, 3, 3, dtype=torch.float32, s=(9 * Cin) ** -0.5, seed=1)
+    b = rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_conv3x3(w.cpu(), b.cpu(), dtype, DEV)
+    kw = dict(stride=stride, pad=pad, upsample=ups, out_hw=ohw)
+    got = ops.conv3x3(x, pw, tile=tile, **kw)
+    # independent statement with F.conv2d on the UNPACKED weight (checks packing order)
+    xi = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xi = torch.nn.functional.interpolate(xi, scale_factor=2, mode="nearest")
+    if ohw is not None:
+        xi = torch.nn.functional.pad(xi, (0, 1, 0, 1))
+    ref = torch.nn.functional.conv2d(xi, w.to(dtype).float(), b, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    check(f"conv3x3 {B}x{H}x{W}x{Cin}->{N} s{stride} p{pad} u{int(ups)} t{tile}", got, ref.to(dtype), dtype)
+    check("conv3x3 vs emu", got, emu.conv3x3(x, pw, **kw), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_fused_epilogue(dtype):
+    B, H, W, Cin, N = 3, 12, 12, 64, 96
+    x = rnd(B, H, W, Cin, dtype=dtype)
+    pw = ops.pack_conv3x3(rnd(N, Cin, 3, 3, dtype=torch.float32, s=0.04, seed=1).cpu(),
+                          rnd(N, dtype=torch.float32, seed=2).cpu(), dtype, DEV)
+    emb = rnd(B, 4 * N, dtype=dtype, seed=3)[:, N:2 * N]          # column slice of a wider embedding matrix
+    big = rnd(B, H, W, N + 32, dtype=dtype, seed=4)
+    res = big[..., 32:]                                            # strided residual (concat-buffer view)
+    oa = torch.zeros(B, H, W, 2 * N, dtype=dtype, device=DEV)
+    ob = torch.zeros_like(oa)
+    ops.conv3x3(x, pw, rowvec=emb, residual=res, out=oa[..., :N])
+    emu.conv3x3(x, pw, rowvec=emb, residual=res, out=ob[..., :N])
+    check("conv3x3 emb+res into concat view", oa, ob, dtype)
+    kw = dict(act=emu.ACT_LRELU, act_param=0.2, upsample=True)
+    check("conv3x3 upsample+lrelu", ops.conv3x3(x, pw, **kw), emu.conv3x3(x, pw, **kw), dtype)
+    pw4 = ops.pack_conv3x3(rnd(4, Cin, 3, 3, dtype=torch.float32, s=0.04, seed=5).cpu(),
+                           rnd(4, dtype=torch.float32, seed=6).cpu(), dtype, DEV)
+    check("conv3x3 N=4 f32", ops.conv3x3(x, pw4, out_f32=True), emu.conv3x3(x, pw4, out_f32=True), torch.float32, 4.0)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+ATT_CASES = [(2, 5, 1024, 1024), (1, 10, 256, 256), (2, 20, 64, 64), (2, 5, 1024, 77), (1, 2, 100, 77),
+             (1, 1, 4096, 4096), (3, 4, 37, 200), (2, 20, 64, 77)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Lq,Lk", ATT_CASES)
+def test_attention(B, H, Lq, Lk, dtype):
+    C = H * 64
+    q_wide = rnd(B, Lq, 2 * C, dtype=dtype)
+    q = q_wide[..., :C] if Lq == Lk else q_wide[..., C:]
+    k = q_wide[..., C:] if Lq == Lk else rnd(B, Lk, C, dtype=dtype, seed=1)
+    Lp = (Lk + 7) // 8 * 8
+    vt = rnd(B, C, Lp, dtype=dtype, seed=2)
+    vt[..., Lk:] = float("nan")    # pad columns must be ignored by the kernel
+    oa = torch.zeros(B, Lq, C, dtype=dtype, device=DEV)
+    ob = torch.zeros_like(oa)
+    ops.attention(q, k, vt, oa, H, Lk, 0.125)
+    emu.attention(q, k, vt, ob, H, Lk, 0.125)
+    check(f"attention B{B} H{H} Lq{Lq} Lk{Lk}", oa, ob, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_peaked_softmax(dtype):
+    """online-softmax rescale path: one key dominates late in the sequence."""
+    B, H, L = 1, 2, 512
+    C = H * 64
+    q, k = rnd(B, L, C, dtype=dtype), rnd(B, L, C, dtype=dtype, seed=1)
+    k[:, 300] = q[:, 7] * 4.0
+    k[:, 17] = q[:, 450] * 3.0
+    vt = rnd(B, C, L, dtype=dtype, seed=2)
+    oa, ob = torch.zeros(B, L, C, dtype=dtype, device=DEV), torch.zeros(B, L, C, dtype=dtype, device=DEV)
+    ops.attention(q, k, vt, oa, H, L, 0.125)
+    emu.attention(q, k, vt, ob, H, L, 0.125)
+    check("attention peaked", oa, ob, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,heads,shift", [(2, 16, 16, 180, 6, 0), (2, 16, 24, 180, 6, 4), (1, 8, 8, 60, 6, 4),
+                                                  (1, 64, 64, 180, 6, 4)])
+def test_window_attention(B, H, W, C, heads, shift, dtype):
+    ld = (3 * C + 7) // 8 * 8
+    Cp = (C + 15) // 16 * 16
+    qkv = rnd(B, H, W, ld, dtype=dtype)
+    table = rnd(225, heads, dtype=torch.float32, s=0.5, seed=1)
+    oa = torch.zeros(B, H, W, Cp, dtype=dtype, device=DEV)
+    ob = torch.zeros_like(oa)
+    sc = (C // heads) ** -0.5
+    ops.window_attention(qkv, oa, table, C, heads, 8, shift, sc)
+    emu.window_attention(qkv, ob, table, C, heads, 8, shift, sc)
+    check(f"window_attention {B}x{H}x{W} C{C} shift{shift}", oa, ob, dtype)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C,silu,eps", [(2, 4096, 320, True, 1e-5), (3, 64, 1280, True, 1e-5),
+                                              (2, 256, 2560, True, 1e-5), (1, 1024, 64, False, 1e-6),
+                                              (2, 100, 960, True, 1e-5), (1, 65536, 128, True, 1e-6)])
+def test_groupnorm(B, HW, C, silu, eps, dtype):
+    x = rnd(B, HW, C, dtype=dtype) * 1.5 + 0.7            # non-zero mean: exercises E[x^2]-mean^2
+    g, b = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=1), 0.1 * rnd(C, dtype=torch.float32, seed=2)
+    check(f"groupnorm B{B} HW{HW} C{C}", ops.groupnorm(x, g, b, eps, silu), emu.groupnorm(x, g, b, eps, silu), dtype)
+    wide = rnd(B, HW, C + 64, dtype=dtype, seed=3)
+    oa, ob = torch.zeros_like(wide), torch.zeros_like(wide)
+    ops.groupnorm(wide[..., 64:], g, b, eps, silu, out=oa[..., :C])
+    emu.groupnorm(wide[..., 64:], g, b, eps, silu, out=ob[..., :C])
+    check("groupnorm strided", oa, ob, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C,Cpad", [(4096, 320, 320), (1001, 1280, 1280), (777, 180, 192), (64, 60, 64),
+                                          (10, 640, 640), (5, 2048, 2048)])
+def test_layernorm(rows, C, Cpad, dtype):
+    x = rnd(rows, Cpad, dtype=dtype) * 2 + 0.3
+    g, b = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=1), 0.1 * rnd(C, dtype=torch.float32, seed=2)
+    check(f"layernorm {rows}x{C}/{Cpad}", ops.layernorm(x, g, b, C), emu.layernorm(x, g, b, C), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_rows(dtype):
+    x = rnd(300, 1088, dtype=dtype, s=3.0)
+    a, b = x.clone(), x.clone()
+    check("softmax_rows", ops.softmax_rows_(a, 1030), emu.softmax_rows_(b, 1030), dtype)
+
+
+# ------------------------------------------------------------------------------------------------ elementwise & co
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_and_elementwise(dtype):
+    a, b = rnd(2, 9, 7, 96, dtype=dtype), rnd(2, 9, 7, 160, dtype=dtype, seed=1)
+    out1, out2 = torch.zeros(2, 9, 7, 200, dtype=dtype, device=DEV), torch.zeros(2, 9, 7, 200, dtype=dtype, device=DEV)
+    ops.add_scaled(a, b[..., 64:], 0.9, out=out1[..., 104:])
+    emu.add_scaled(a, b[..., 64:], 0.9, out=out2[..., 104:])
+    check("add_scaled strided", out1, out2, dtype)
+    x0, x1 = rnd(2, 4, 10, 6, dtype=torch.float32), rnd(2, 4, 10, 6, dtype=torch.float32, seed=1)
+    check("nchw_to_nhwc cat", ops.nchw_to_nhwc(x0, x1, 8, dtype, 2.0, -1.0), emu.nchw_to_nhwc(x0, x1, 8, dtype, 2.0, -1.0), dtype)
+    check("nchw_to_nhwc pad", ops.nchw_to_nhwc(x0, None, 8, dtype), emu.nchw_to_nhwc(x0, None, 8, dtype), dtype)
+    y = rnd(2, 5, 6, 16, dtype=dtype)
+    sh = rnd(3, dtype=torch.float32, seed=2)
+    check("nhwc_to_nchw", ops.nhwc_to_nchw(y, 3, 0.5, sh), emu.nhwc_to_nchw(y, 3, 0.5, sh), torch.float32)
+    yf = rnd(2, 5, 6, 8, dtype=torch.float32)
+    check("nhwc_to_nchw f32", ops.nhwc_to_nchw(yf, 4, 0.18215), emu.nhwc_to_nchw(yf, 4, 0.18215), torch.float32)
+    img = rnd(2, 3, 32, 48, dtype=torch.float32).abs()
+    mean = torch.tensor([0.4488, 0.4371, 0.4040], device=DEV)
+    check("pixel_unshuffle", ops.pixel_unshuffle(img, 8, 192, mean, 1.0, dtype), emu.pixel_unshuffle(img, 8, 192, mean, 1.0, dtype), dtype)
+    t = torch.tensor([999.0, 381.0, 949.0365, 0.0], device=DEV)
+    check("timestep_embedding", ops.timestep_embedding(t, 320, dtype), emu.timestep_embedding(t, 320, dtype), dtype, scale=2.0)
+
+
+def test_sampler_and_tiles_f32():
+    B, n = 3, 4 * 20 * 24
+    x, oc, ou, nz = (rnd(B, 4, 20, 24, dtype=torch.float32, seed=i) for i in range(4))
+    co = [rnd(B, dtype=torch.float32, seed=10 + i) for i in range(5)]
+    check("spaced_step cfg", ops.spaced_step(x, oc, ou, nz, 4.0, *co), emu.spaced_step(x, oc, ou, nz, 4.0, *co), torch.float32, 0.05)
+    check("spaced_step nocfg", ops.spaced_step(x, oc, None, nz, 1.0, *co), emu.spaced_step(x, oc, None, nz, 1.0, *co), torch.float32, 0.05)
+    check("lincomb4", ops.lincomb4(x, co[0], oc, co[1], ou, co[2]), emu.lincomb4(x, co[0], oc, co[1], ou, co[2]), torch.float32, 0.05)
+    import numpy as np
+    from diffbir_amd.utils.common import gaussian_weights, sliding_windows
+    H, W, ts, st = 75, 89, 64, 32
+    xx = rnd(2, 4, H, W, dtype=torch.float32)
+    coords = torch.tensor([[a, c] for a, _, c, _ in sliding_windows(H, W, ts, st)], dtype=torch.int32, device=DEV)
+    tiles = ops.tile_gather(xx, coords, ts)
+    assert torch.equal(tiles, emu.tile_gather(xx, coords, ts))
+    wt = torch.tensor(gaussian_weights(ts, ts), dtype=torch.float32, device=DEV)
+    ev = rnd(*tiles.shape, dtype=torch.float32, seed=5)
+    check("tile_accumulate", ops.tile_accumulate(ev, wt, coords, 2, H, W), emu.tile_accumulate(ev, wt, coords, 2, H, W), torch.float32, 0.01)
+
+
+def test_image_io_f32():
+    u8 = torch.randint(0, 256, (2, 40, 56, 3), dtype=torch.uint8, device=DEV)
+    f = ops.u8_to_f32_nchw(u8)
+    assert torch.equal(f, emu.u8_to_f32_nchw(u8))
+    for r in (1, 2, 4, 8, 16):
+        check(f"wavelet_blur r{r}", ops.wavelet_blur(f, r), emu.wavelet_blur(f, r), torch.float32, 0.01)
+    assert torch.equal(ops.f32_nchw_to_u8_nhwc(f * 1.1 - 0.05), emu.f32_nchw_to_u8_nhwc(f * 1.1 - 0.05))
+    check("colorfix", ops.colorfix(f, f * 0.5, f * 0.25), emu.colorfix(f, f * 0.5, f * 0.25), torch.float32, 0.01)

@@ -1,0 +1,139 @@
+"""-m gpu: end-to-end parity of the engine (HIP kernels on the MI355X) against golden vectors produced by the
+unmodified reference on CPU fp32 (tests/golden, oracle/make_golden.py) — same seeded weights, inputs and noise.
+
+Tolerance: BASELINE.json north_star — PSNR >= 45 dB on the restored uint8 image for fp16 at the full configuration;
+module-level relative-L2 bounds below are those of 16-bit activations through ~100 layers."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from tests.helpers import build_engine, rel_err, run_pipe
+
+pytestmark = pytest.mark.gpu
+REPORT = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _report():
+    yield
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "pipeline_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    from diffbir_amd import native
+    native.lib()
+    return torch.device("cuda:0")
+
+
+MOD_TOL = {torch.float16: 1.0e-2, torch.bfloat16: 6e-2}
+
+
+@pytest.mark.parametrize("cfg,img", [("tiny", 128), ("full", 256)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@torch.no_grad()
+def test_modules_vs_reference_golden(golden_dir, cfg, img, dtype):
+    dev = _dev()
+    gm = np.load(os.path.join(golden_dir, f"{cfg}_modules.npz"))
+    pipe, cldm, swin = build_engine(cfg, "DIFFUSION_V21", dev, dtype)
+    rs = cases.NoiseStream(7)
+    x = torch.tensor(cases.make_lq(11, 2, img, img)).float().div(255).permute(0, 3, 1, 2).contiguous().to(dev)
+    res = {}
+    res["swinir"] = rel_err(swin(x), gm["swinir_out"])
+    res["vae_mode"] = rel_err(cldm.vae.encode_mode(x, 0.18215, 2.0, -1.0), gm["vae_mode"])
+    z = rs((2, 4, img // 8, img // 8)).to(dev)
+    res["vae_dec"] = rel_err(cldm.vae_decode(z), gm["vae_dec"])
+    c_txt = cldm.clip(torch.tensor(gm["tokens"]))
+    res["c_txt"] = rel_err(c_txt, gm["c_txt"])
+    xn = rs((2, 4, img // 8, img // 8)).to(dev)
+    c_img = (rs((2, 4, img // 8, img // 8)) * 0.5).to(dev)
+    cldm.control_scales = [0.9] * 13
+    res["eps_int_t"] = rel_err(cldm(xn, torch.tensor([999, 381], device=dev), dict(c_txt=c_txt, c_img=c_img)), gm["eps_int_t"])
+    res["eps_float_t"] = rel_err(cldm(xn, torch.tensor([949.0365, 49.95], device=dev), dict(c_txt=c_txt, c_img=c_img)),
+                                 gm["eps_float_t"])
+    ctrl = cldm.controlnet(xn, c_img, torch.tensor([999, 381], device=dev), c_txt)
+    res["control_0"] = rel_err(ctrl[0].permute(0, 3, 1, 2), gm["control_0"])
+    res["control_12"] = rel_err(ctrl[12].permute(0, 3, 1, 2), gm["control_12"])
+    REPORT[f"modules_{cfg}_{dtype}"] = {k: v[0] for k, v in res.items()}
+    print(cfg, dtype, {k: f"{v[0]:.2e}" for k, v in res.items()})
+    tol = MOD_TOL[dtype]
+    bad = {k: v[0] for k, v in res.items() if not (v[0] < (1e-4 if k == "c_txt" else tol))}
+    assert not bad, bad
+
+
+CASES = [
+    ("spaced6_v21", "DIFFUSION_V21", (3, 1, 512, 512), 6, "spaced", 231, {}),
+    ("dpm10_v21", "DIFFUSION_V21", (3, 1, 512, 512), 10, "dpm++_m2", 231, {}),
+    ("spaced6_v2", "DIFFUSION_V2", (3, 1, 512, 512), 6, "spaced", 231, {}),
+    ("spaced4_b2_v21", "DIFFUSION_V21", (5, 2, 512, 512), 4, "spaced", 99, {}),
+    ("spaced3_pad_v21", "DIFFUSION_V21", (9, 1, 600, 712), 3, "spaced", 5, {}),
+    ("spaced3_tiled_v21", "DIFFUSION_V21", (9, 1, 600, 712), 3, "spaced", 5, dict(tiled=True)),
+    ("dpm10_tiled_v21", "DIFFUSION_V21", (9, 1, 600, 712), 10, "dpm++_m2", 5, dict(tiled=True)),
+]
+
+
+@pytest.mark.parametrize("dtype,min_psnr", [(torch.float16, 45.0), (torch.bfloat16, 32.0)])
+@pytest.mark.parametrize("name,dcfg,lqspec,steps,sampler,seed,kw", CASES, ids=[c[0] for c in CASES])
+def test_tiny_pipeline_vs_reference_golden(golden_dir, name, dcfg, lqspec, steps, sampler, seed, kw, dtype, min_psnr):
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", dcfg, dev, dtype)
+    ref = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))[name]
+    out = run_pipe(pipe, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+    psnr = cases.psnr_u8(out, ref)
+    REPORT[f"tiny_{name}_{dtype}"] = psnr
+    print(name, dtype, f"PSNR {psnr:.2f} dB")
+    assert out.shape == ref.shape and psnr >= min_psnr, psnr
+
+
+def test_full_pipeline_50_steps_vs_reference_golden(golden_dir):
+    """BASELINE config C1/C2 semantics at batch 1: 512x512, 50 spaced steps, CFG 4.0, v2.1 — PSNR >= 45 dB (fp16)
+    against the unmodified reference's CPU fp32 output."""
+    dev = _dev()
+    pipe, cldm, swin = build_engine("full", "DIFFUSION_V21", dev, torch.float16)
+    ref = np.load(os.path.join(golden_dir, "full_pipeline.npz"))["spaced50_v21"]
+    out = run_pipe(pipe, cases.make_lq(3, 1, 512, 512), 50, "spaced", 231)
+    psnr = cases.psnr_u8(out, ref)
+    REPORT["full_spaced50_v21_fp16"] = psnr
+    print(f"full 50-step pipeline PSNR {psnr:.2f} dB")
+    assert psnr >= 45.0, psnr
+
+
+def test_tiled_equals_untiled_when_single_tile():
+    """size-independent property: with one tile covering the whole latent the tiled scheduler is the identity."""
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    lq = cases.make_lq(3, 1, 512, 512)
+    a = run_pipe(pipe, lq, 2, "spaced", 7)
+    b = run_pipe(pipe, lq, 2, "spaced", 7, tiled=True, tile=512, stride=256)
+    assert cases.psnr_u8(a, b) > 60.0   # (eps*w)/w is not bit-exactly eps in f32
+
+
+def test_batch_independence():
+    """images are independent units (the data-parallel sharding property): a batch of 2 equals two batches of 1
+    given the same per-sample noise."""
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    lq = cases.make_lq(5, 2, 512, 512)
+    full = cases.NoiseStream(11)
+    draws = []
+
+    def rec(shape):
+        t = full(shape)
+        draws.append(t)
+        return t
+    pipe.randn = rec
+    args = (3, 1.0, False, 512, 256, False, 256, False, 256, False, 512, 256, "", cases.NEG_PROMPT, 4.0, "noise",
+            "spaced", 0, False, 0, 0, 300, 1, 1, 1)
+    both = pipe.run(lq, *args)
+    for i in range(2):
+        it = iter([d[i:i + 1] for d in draws])
+        pipe.randn = lambda shape: next(it)
+        one = pipe.run(lq[i:i + 1], *args)
+        assert cases.psnr_u8(one, both[i:i + 1]) > 55.0
