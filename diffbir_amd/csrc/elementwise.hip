@@ -175,7 +175,9 @@ __global__ void u8_to_f32_nchw_kernel(const unsigned char* __restrict__ src, flo
     const long long bc = i / HW;
     const int c = (int)(bc % 3);
     const long long b = bc / 3;
-    const float v = (float)src[(b * HW + p) * 3 + c] / 255.0f;
+    // correctly rounded x/255 (== torch .div(255)): the f64 quotient rounds to the same f32 for all 256 inputs,
+    // independent of the compiler's f32 division lowering
+    const float v = (float)((double)src[(b * HW + p) * 3 + c] / 255.0);
     dst[i] = fminf(fmaxf(v, 0.f), 1.f);
   }
 }

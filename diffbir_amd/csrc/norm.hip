@@ -6,7 +6,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // GroupNorm, three launches:
 //  1. gn_partial : grid (nchunk, B). Thread owns one 8-channel vector (16 B loads, coalesced along C) and walks
-//                  the chunk's rows; per-channel (sum, sumsq) reduced through LDS atomics -> partial[b][chunk][2C].
+//                  the chunk's rows; per-channel (sum, sumsq) combined through LDS in a fixed order
+//                  -> partial[b][chunk][2C] (deterministic: no float atomics anywhere).
 //  2. gn_finalize: grid (B). Sums the chunks, reduces channels -> groups, emits per-(b,c) affine coefficients
 //                  a = rstd*gamma, s = beta - mean*rstd*gamma.
 //  3. gn_apply   : y = act(x*a + s), vectorised elementwise.
@@ -14,12 +15,10 @@ namespace {
 template <typename T>
 __global__ void gn_partial(const u16* __restrict__ x, long long ldx, float* __restrict__ partial, int HW, int C,
                            int rows_per_chunk, int rpi) {
-  extern __shared__ float sh[];  // [2*C]
+  extern __shared__ float sh[];  // [rpi][2*C]: per row-subset partial sums, combined in a FIXED order below
   const int CV = C >> 3;
   const int t = threadIdx.x;
   const int b = blockIdx.y, chunk = blockIdx.x;
-  for (int i = t; i < 2 * C; i += blockDim.x) sh[i] = 0.f;
-  __syncthreads();
   const int cv = t % CV, rsub = t / CV;
   const int r_begin = chunk * rows_per_chunk;
   const int r_end = min(HW, r_begin + rows_per_chunk);
@@ -37,49 +36,55 @@ __global__ void gn_partial(const u16* __restrict__ x, long long ldx, float* __re
       ss[e] += f[e] * f[e];
     }
   }
+  float* mine = sh + (long long)rsub * 2 * C;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    atomicAdd(&sh[cv * 8 + e], s[e]);
-    atomicAdd(&sh[C + cv * 8 + e], ss[e]);
+    mine[cv * 8 + e] = s[e];
+    mine[C + cv * 8 + e] = ss[e];
   }
   __syncthreads();
+  // deterministic combine (no float atomics: results are bit-reproducible run to run and batch-size independent)
   float* out = partial + ((long long)b * gridDim.x + chunk) * 2 * C;
-  for (int i = t; i < 2 * C; i += blockDim.x) out[i] = sh[i];
+  for (int i = t; i < 2 * C; i += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < rpi; ++k) a += sh[(long long)k * 2 * C + i];
+    out[i] = a;
+  }
 }
 
 __global__ void gn_finalize(const float* __restrict__ partial, const float* __restrict__ gamma,
                             const float* __restrict__ beta, float* __restrict__ coef, int nchunk, int HW, int C,
                             int groups, float eps) {
-  extern __shared__ float sh[];  // [2*groups] sums, then [2*groups] mean/rstd
+  extern __shared__ float sh[];  // [2*C] per-channel sums, then [2*groups] mean / rstd
   const int b = blockIdx.x, t = threadIdx.x;
   const int cpg = C / groups;
-  for (int i = t; i < 2 * groups; i += blockDim.x) sh[i] = 0.f;
-  __syncthreads();
   const float* pb = partial + (long long)b * nchunk * 2 * C;
-  for (int c = t; c < C; c += blockDim.x) {
-    float s = 0.f, ss = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
-      s += pb[(long long)k * 2 * C + c];
-      ss += pb[(long long)k * 2 * C + C + c];
-    }
-    atomicAdd(&sh[c / cpg], s);
-    atomicAdd(&sh[groups + c / cpg], ss);
+  for (int c = t; c < 2 * C; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += pb[(long long)k * 2 * C + c];
+    sh[c] = s;
   }
   __syncthreads();
+  float* stat = sh + 2 * C;
   if (t < groups) {
+    float s = 0.f, ss = 0.f;
+    for (int c = t * cpg; c < (t + 1) * cpg; ++c) {
+      s += sh[c];
+      ss += sh[C + c];
+    }
     const float n = (float)HW * (float)cpg;
-    const float mean = sh[t] / n;
-    const float var = fmaxf(sh[groups + t] / n - mean * mean, 0.f);
-    sh[2 * groups + t] = mean;
-    sh[3 * groups + t] = rsqrtf(var + eps);
+    const float mean = s / n;
+    const float var = fmaxf(ss / n - mean * mean, 0.f);
+    stat[t] = mean;
+    stat[groups + t] = rsqrtf(var + eps);
   }
   __syncthreads();
   float* cb = coef + (long long)b * 2 * C;
   for (int c = t; c < C; c += blockDim.x) {
     const int g = c / cpg;
-    const float a = sh[3 * groups + g] * gamma[c];
+    const float a = stat[groups + g] * gamma[c];
     cb[c] = a;
-    cb[C + c] = beta[c] - sh[2 * groups + g] * a;
+    cb[C + c] = beta[c] - stat[g] * a;
   }
 }
 
@@ -226,7 +231,7 @@ extern "C" int dbir_groupnorm(int dtype, const void* x, long long ldx, void* y, 
                               const float* beta, int B, int HW, int C, int groups, float eps, int silu,
                               float* workspace, void* stream) {
   DBIR_CHECK_ARG(x && y && gamma && beta && workspace, "dbir_groupnorm: null pointer");
-  DBIR_CHECK_ARG(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 8192,
+  DBIR_CHECK_ARG(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 4096,
                  "dbir_groupnorm: need C%%8==0, C%%groups==0, ld%%8==0 (C=%d)", C);
   DBIR_CHECK_ARG(groups <= 64, "dbir_groupnorm: groups must be <= 64");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -238,7 +243,7 @@ extern "C" int dbir_groupnorm(int dtype, const void* x, long long ldx, void* y, 
   DBIR_CHECK_ARG(threads <= 1024, "dbir_groupnorm: C too large");
   float* partial = workspace;
   float* coef = workspace + (long long)B * nchunk * 2 * C;
-  const size_t sh1 = (size_t)2 * C * sizeof(float);
+  const size_t sh1 = (size_t)rpi * 2 * C * sizeof(float);
   const long long total_vec = (long long)B * HW * CV;
   const int ablocks = (int)((total_vec + 255) / 256 > 4096 ? 4096 : (total_vec + 255) / 256);
   if (dtype == DBIR_F16) {
@@ -251,7 +256,7 @@ extern "C" int dbir_groupnorm(int dtype, const void* x, long long ldx, void* y, 
     dbir_set_error("dbir_groupnorm: bad dtype");
     return DBIR_ERR_ARG;
   }
-  hipLaunchKernelGGL(gn_finalize, dim3(B), dim3(256), 4 * groups * sizeof(float), s, partial, gamma, beta, coef,
+  hipLaunchKernelGGL(gn_finalize, dim3(B), dim3(256), (size_t)(2 * C + 2 * groups) * sizeof(float), s, partial, gamma, beta, coef,
                      nchunk, HW, C, groups, eps);
   if (dtype == DBIR_F16)
     hipLaunchKernelGGL((gn_apply<F16>), dim3(ablocks), dim3(256), 0, s, (const u16*)x, ldx, (u16*)y, ldy, coef, HW,

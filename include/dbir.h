@@ -82,7 +82,8 @@ typedef struct dbir_gemm_desc {
   int store_mode, trans_L;
   long long trans_ld, trans_bstride;
   int batch;
-  int tile; /* 0 = auto; 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64 (testing / tuning) */
+  int tile; /* 0 = auto; generic kernel 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64; direct-to-LDS kernel 5: 128x128,
+               6: 256x64, 7: 64x256 (testing / tuning) */
 } dbir_gemm_desc;
 int dbir_gemm(const dbir_gemm_desc* d, void* stream);
 

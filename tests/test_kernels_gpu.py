@@ -186,6 +186,119 @@ def test_conv3x3_fused_epilogue(dtype):
     check("conv3x3 N=4 f32", ops.conv3x3(x, pw4, out_f32=True), emu.conv3x3(x, pw4, out_f32=True), torch.float32, 4.0)
 
 
+# ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
+GLDS_TILES = [5, 6, 7]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", GLDS_TILES)
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (130, 72, 64), (257, 200, 1024), (4096, 640, 2560), (3, 1280, 320),
+                                   (513, 1288, 128)])
+def test_glds_linear(M, N, K, tile, dtype):
+    x = rnd(M, K, dtype=dtype)
+    w, b = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    got = ops.linear(x, pw, tile=tile)
+    ref = (x.float() @ w.to(dtype).float().t() + b).to(dtype)      # independent statement on the unpacked weight
+    check(f"glds linear {M}x{N}x{K} t{tile}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", GLDS_TILES)
+@pytest.mark.parametrize("act", [emu.ACT_NONE, emu.ACT_SILU, emu.ACT_GELU, emu.ACT_LRELU])
+def test_glds_linear_epilogue(act, tile, dtype):
+    M, N, K, rpb = 384, 200, 192, 96
+    x = rnd(M, K + 24, dtype=dtype)[:, :K]                             # strided A (ld > K)
+    w, b = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    res = rnd(M, N + 8, dtype=dtype, seed=3)[:, :N]                    # strided residual
+    rv = rnd(M // rpb, N + 16, dtype=dtype, seed=4)[:, 8:8 + N]        # strided, offset row vector
+    out_a = torch.zeros(M, N + 40, dtype=dtype, device=DEV)
+    out_b = torch.zeros(M, N + 40, dtype=dtype, device=DEV)
+    kw = dict(act=act, act_param=0.2, out_scale=0.7, residual=res, rowvec=rv, rows_per_batch=rpb)
+    ops.linear(x, pw, out=out_a[:, 16:16 + N], tile=tile, **kw)
+    emu.linear(x, pw, out=out_b[:, 16:16 + N], **kw)
+    check(f"glds linear epilogue act{act} t{tile}", out_a, out_b, dtype, scale=1.5)  # also: nothing outside the view
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", GLDS_TILES)
+@pytest.mark.parametrize("M,Nh,K", [(512, 1280, 320), (100, 64, 64), (333, 96, 128)])
+def test_glds_geglu(M, Nh, K, tile, dtype):
+    x = rnd(M, K, dtype=dtype)
+    w, b = rnd(2 * Nh, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(2 * Nh, dtype=torch.float32, seed=2)
+    pw = ops.pack_geglu(w.cpu(), b.cpu(), dtype, DEV)
+    h = x.float() @ w.to(dtype).float().t() + b
+    ref = (h[:, :Nh] * torch.nn.functional.gelu(h[:, Nh:])).to(dtype)
+    check(f"glds geglu {M}x{Nh}x{K} t{tile}", ops.linear(x, pw, tile=tile), ref, dtype)
+    res = rnd(M, Nh, dtype=dtype, seed=5)
+    check("glds geglu+res", ops.linear(x, pw, residual=res, tile=tile), emu.linear(x, pw, residual=res), dtype, 1.5)
+
+
+GLDS_CONV_CASES = [
+    # B, H, W, Cin, N, stride, pad, upsample, out_hw
+    (2, 16, 16, 64, 128, 1, 1, False, None), (1, 20, 12, 128, 320, 1, 1, False, None),
+    (2, 16, 16, 64, 64, 2, 1, False, None), (2, 16, 16, 64, 40, 2, 0, False, (8, 8)),
+    (2, 8, 8, 128, 128, 1, 1, True, None), (1, 17, 13, 192, 200, 1, 1, False, None),
+    (2, 8, 8, 1280, 1280, 1, 1, False, None), (1, 64, 64, 320, 320, 1, 1, False, None),
+    (1, 15, 15, 64, 64, 2, 1, False, None), (3, 6, 10, 64, 72, 1, 1, True, None),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", GLDS_TILES)
+@pytest.mark.parametrize("B,H,W,Cin,N,stride,pad,ups,ohw", GLDS_CONV_CASES)
+def test_glds_conv3x3(B, H, W, Cin, N, stride, pad, ups, ohw, tile, dtype):
+    x = rnd(B, H, W, Cin, dtype=dtype)
+    w = rnd(N, Cin, 3, 3, dtype=torch.float32, s=(9 * Cin) ** -0.5, seed=1)
+    b = rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_conv3x3(w.cpu(), b.cpu(), dtype, DEV)
+    got = ops.conv3x3(x, pw, tile=tile, stride=stride, pad=pad, upsample=ups, out_hw=ohw)
+    xi = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xi = torch.nn.functional.interpolate(xi, scale_factor=2, mode="nearest")
+    if ohw is not None:
+        xi = torch.nn.functional.pad(xi, (0, 1, 0, 1))
+    ref = torch.nn.functional.conv2d(xi, w.to(dtype).float(), b, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    check(f"glds conv3x3 {B}x{H}x{W}x{Cin}->{N} s{stride} p{pad} u{int(ups)} t{tile}", got, ref.to(dtype), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", GLDS_TILES)
+def test_glds_conv3x3_fused_epilogue(tile, dtype):
+    B, H, W, Cin, N = 3, 12, 12, 64, 96
+    x = rnd(B, H, W, Cin, dtype=dtype)
+    pw = ops.pack_conv3x3(rnd(N, Cin, 3, 3, dtype=torch.float32, s=0.04, seed=1).cpu(),
+                          rnd(N, dtype=torch.float32, seed=2).cpu(), dtype, DEV)
+    emb = rnd(B, 4 * N, dtype=dtype, seed=3)[:, N:2 * N]          # column slice of a wider embedding matrix
+    res = rnd(B, H, W, N + 32, dtype=dtype, seed=4)[..., 32:]      # strided residual (concat-buffer view)
+    oa = torch.zeros(B, H, W, 2 * N, dtype=dtype, device=DEV)
+    ob = torch.zeros_like(oa)
+    ops.conv3x3(x, pw, rowvec=emb, residual=res, out=oa[..., :N], tile=tile)
+    emu.conv3x3(x, pw, rowvec=emb, residual=res, out=ob[..., :N])
+    check(f"glds conv3x3 emb+res into concat view t{tile}", oa, ob, dtype, scale=1.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_glds_bmm_nt(dtype):
+    Z, M, K = 3, 200, 128
+    qk = rnd(Z, M, 2 * K, dtype=dtype)                     # q / k views with row stride 2K (VAE attention layout)
+    out = torch.zeros(Z, M, M + 56, dtype=dtype, device=DEV)
+    ref = torch.zeros_like(out)
+    ops.bmm_nt(qk[..., :K], qk[..., K:], out[..., :M], out_scale=0.3)
+    emu.bmm_nt(qk[..., :K], qk[..., K:], ref[..., :M], out_scale=0.3)
+    check("glds bmm_nt strided (Wrows == N, not padded)", out, ref, dtype)
+
+
+def test_glds_deterministic():
+    """same launch twice -> bit-identical output (no atomics / race in the pipeline)."""
+    x = rnd(2, 32, 32, 320, dtype=torch.float16)
+    pw = ops.pack_conv3x3(rnd(320, 320, 3, 3, dtype=torch.float32, s=0.02, seed=1).cpu(), None, torch.float16, DEV)
+    a = ops.conv3x3(x, pw).clone()
+    for _ in range(5):
+        assert torch.equal(a, ops.conv3x3(x, pw))
+
+
 # ------------------------------------------------------------------------------------------------ attention
 ATT_CASES = [(2, 5, 1024, 1024), (1, 10, 256, 256), (2, 20, 64, 64), (2, 5, 1024, 77), (1, 2, 100, 77),
              (1, 1, 4096, 4096), (3, 4, 37, 200), (2, 20, 64, 77)]
@@ -316,7 +429,8 @@ def test_sampler_and_tiles_f32():
 def test_image_io_f32():
     u8 = torch.randint(0, 256, (2, 40, 56, 3), dtype=torch.uint8, device=DEV)
     f = ops.u8_to_f32_nchw(u8)
-    assert torch.equal(f, emu.u8_to_f32_nchw(u8))
+    # true division like the CPU reference that generated the goldens (torch's GPU div-by-scalar multiplies by 1/255)
+    assert torch.equal(f.cpu(), emu.u8_to_f32_nchw(u8.cpu()))
     for r in (1, 2, 4, 8, 16):
         check(f"wavelet_blur r{r}", ops.wavelet_blur(f, r), emu.wavelet_blur(f, r), torch.float32, 0.01)
     assert torch.equal(ops.f32_nchw_to_u8_nhwc(f * 1.1 - 0.05), emu.f32_nchw_to_u8_nhwc(f * 1.1 - 0.05))
