@@ -103,7 +103,7 @@ def measure_roofline(cldm, device, batch):
     torch.cuda.synchronize()
     rec = ops.stop_profile()
     tot = {}
-    for kind, flops, e0, e1 in rec:
+    for kind, flops, e0, e1, _tag in rec:
         ms = e0.elapsed_time(e1)
         a = tot.setdefault(kind, [0.0, 0.0, 0])
         a[0] += flops

@@ -1,23 +1,25 @@
-// Implicit-GEMM (linear / 1x1 / 3x3 convolution) on gfx950 MFMA, direct-to-LDS staged variant.
+// Implicit-GEMM (linear / 1x1 / 3x3 convolution) on gfx950 MFMA, direct-to-LDS staged, multi-stage ring.
 //
 // This is the hot kernel of the engine: every conv3x3 with Cin % 64 == 0 and every linear with K % 64 == 0
 // of the UNet / ControlNet / VAE / SwinIR (i.e. all of them except the 4-/8-channel stem convs) runs here.
 // The generic register-staged kernel in gemm.hip remains as the fallback for the odd shapes and for the
 // f32 / transposed stores.
 //
-// Structure (cdna_hip_programming.md §5, "step 3" + T2):
-//   * 256 threads = 4 wave64, each wave owns a 64x64 output tile = 2x2 v_mfma_f32_32x32x16 accumulators;
-//     the waves are arranged WM x WN so one template gives 128x128 (2x2), 256x64 (4x1) and 64x256 (1x4)
-//     block tiles.  BK = 64 halfs = one 128-byte line per tile row.
+// Structure (cdna_hip_programming.md §5 / T2 / T3+T4):
+//   * WM x WN wave64 per block, each wave owns a (32*MI) x (32*NJ) output tile of v_mfma_f32_32x32x16
+//     accumulators; BK = 64 halfs = one 128-byte line per tile row.  One template gives the 128x128 / 256x64
+//     (256 threads, 2 blocks per CU) and the 256x128 / 256x256 (1 block per CU, 3-/2-stage ring) variants.
 //   * Both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round trip).
 //     The LDS image is lane-linear, so the bank-conflict swizzle is applied on the SOURCE address: LDS chunk
-//     position `cpos` of row r holds logical 16-byte chunk `cpos ^ (r & 7)`; the MFMA fragment ds_read_b128
-//     applies the same XOR (guide rule 21).
+//     position `cpos` of row r holds logical 16-byte chunk `cpos ^ ((r >> 1) & 7)`; the MFMA fragment
+//     ds_read_b128 applies the same XOR (guide rule 21).  With 128-byte rows two consecutive rows fill one
+//     256-byte bank row, so this key makes the 16 lanes of every ds_read_b128 service group (16 distinct
+//     rows mod 16, same logical chunk) hit 16 distinct 16-byte slots: conflict-free.
 //   * conv3x3 is an implicit GEMM whose K order is (tap, channel); Cin % 64 == 0 makes every K tile lie inside
 //     one tap, so a tile row is one contiguous 128-byte run of the NHWC input at a per-row pixel offset that
 //     only changes when the tap changes.  Padding rows / taps outside the image read a 256-byte zero page.
-//   * double-buffered LDS, tile t+1 in flight while tile t is multiplied; one barrier per K tile;
-//     2 blocks per CU (64 KiB LDS each) interleave to cover the barrier drain.
+//   * STAGES-deep LDS ring, tiles t+1 .. t+STAGES-1 in flight while tile t is multiplied: counted
+//     `s_waitcnt vmcnt(N)` (never a drain in steady state) + ONE raw s_barrier per K tile.
 //   * MFMA orientation is D[n][m] (first operand = weight rows) so that a lane holds 4 consecutive output
 //     channels of one pixel: the f32 epilogue (bias, time-embedding row vector, SiLU/GELU/LeakyReLU/GEGLU,
 //     scale) runs in registers, the 16-bit tile is transposed through LDS and written with 16-byte row-contiguous
@@ -38,17 +40,43 @@ struct G2Params {
   int nkc;      // K tiles per tap (conv) / total K tiles (linear)
   int ntaps;    // 9 (conv) / 1 (linear)
   int mtiles, ntiles;
+  int vec_bias, vec_rv;  // bias / row vector may be read with 16 B / 8 B vector loads
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const G2Params p) {
-  static_assert(WM * WN == 4, "4 waves");
-  constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int RA = BM / 32, RB = BN / 32;  // tile rows staged per thread
+// exact-GELU with erf from Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the 16-bit output ulp):
+// ~12 VALU + 1 exp + 1 rcp instead of the branchy library erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x|/sqrt2)
+  const float erfv = x < 0.f ? -e : e;
+  return 0.5f * x * (1.0f + erfv);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2Params p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
+  constexpr int RPP = NT / 8;                  // tile rows covered by one glds pass of the whole block
+  constexpr int PASS_BYTES = NT * 16;
+  constexpr int RA = BM / RPP, RB = BN / RPP;  // glds per thread per stage for the activation / weight tile
+  constexpr int LOADS = RA + RB;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the pass height");
+  static_assert(STAGES >= 2 && (STAGES - 1) * LOADS < 64, "vmcnt is 6 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const dbir_gemm_desc& d = p.d;
@@ -72,19 +100,19 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const G2Params p) {
   const u16* __restrict__ Wg = reinterpret_cast<const u16*>(d.W) + (long long)bz * d.strideW_z;
   const u16* zp = reinterpret_cast<const u16*>(g_zero_page);
 
-  // ---- staging roles: thread handles LDS chunk position (row = (tid>>3) + 32*i, cpos = tid&7) ----
+  // ---- staging roles: thread handles LDS chunk position (row = (tid>>3) + RPP*i, cpos = tid&7) ----
   const int srow = tid >> 3;
-  const int cch = ((tid & 7) ^ (srow & 7)) * 8;  // logical K offset (halfs) of the chunk this thread fetches
+  const int cch = ((tid & 7) ^ ((srow >> 1) & 7)) * 8;  // logical K offset (halfs) of the chunk this thread fetches
   const bool conv = d.mode == DBIR_MODE_CONV3X3;
 
-  int a_pix0[RA];     // conv: b*Hi*Wi ; linear: unused
-  int a_yx0[RA];      // conv: (iy0 << 16) | (ix0 & 0xffff), virtual coords of tap (0,0)
-  bool a_ok[RA];      // row < M
-  const u16* a_rp[RA];  // current row pointer (tap applied), nullptr-equivalent = zero page when invalid
+  int a_pix0[RA];       // conv: b*Hi*Wi
+  int a_yx0[RA];        // conv: iy0 * 65536 + (ix0 & 0xffff), virtual coords of tap (0,0)
+  bool a_ok[RA];        // row < M
+  const u16* a_rp[RA];  // current row pointer (tap applied); zero page when invalid
   bool a_rv[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int m = tm * BM + srow + 32 * i;
+    const int m = tm * BM + srow + RPP * i;
     a_ok[i] = m < M;
     if (conv) {
       const int hw = d.Ho * d.Wo;
@@ -107,13 +135,13 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const G2Params p) {
   bool w_rv[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int n = tn * BN + srow + 32 * i;
+    const int n = tn * BN + srow + RPP * i;
     w_rv[i] = n < d.Wrows;
     w_rp[i] = w_rv[i] ? Wg + (long long)n * d.Kpad + cch : zp;
   }
 
-  // staging cursor (uniform): tile index, tap, channel-tile within the tap
-  int s_kt = 0, s_tap = 0, s_cc = 0;
+  // staging cursor (uniform): tile index, tap, channel-tile within the tap, ring slot
+  int s_kt = 0, s_tap = 0, s_cc = 0, s_slot = 0;
 
 #define SET_TAP()                                                                                   \
   do {                                                                                              \
@@ -133,22 +161,23 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const G2Params p) {
     }                                                                                               \
   } while (0)
 
-// issue the direct-to-LDS loads of K tile s_kt into buffer (buf_), then advance the cursor
-#define STAGE(buf_)                                                                                 \
+// issue the direct-to-LDS loads of K tile s_kt into ring slot s_slot, then advance the cursor
+#define STAGE()                                                                                     \
   do {                                                                                              \
-    char* ab_ = smem + (buf_) * BUF_BYTES + wave * 1024;                                            \
+    char* ab_ = smem + s_slot * BUF_BYTES + wave * 1024;                                            \
     char* bb_ = ab_ + A_BYTES;                                                                      \
     const int koff_ = s_cc * BK;                                                                    \
     _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                                \
       const u16* src_ = a_rv[i] ? a_rp[i] + koff_ : zp;                                             \
-      __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(ab_ + i * 4096), 16, 0, 0);           \
+      __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(ab_ + i * PASS_BYTES), 16, 0, 0);     \
     }                                                                                               \
     const long long woff_ = (long long)s_kt * BK;                                                   \
     _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                \
       const u16* src_ = w_rv[i] ? w_rp[i] + woff_ : zp;                                             \
-      __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(bb_ + i * 4096), 16, 0, 0);           \
+      __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(bb_ + i * PASS_BYTES), 16, 0, 0);     \
     }                                                                                               \
     ++s_kt;                                                                                         \
+    s_slot = (s_slot + 1 == STAGES) ? 0 : s_slot + 1;                                               \
     if (++s_cc == p.nkc) {                                                                          \
       s_cc = 0;                                                                                     \
       ++s_tap;                                                                                      \
@@ -156,43 +185,51 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const G2Params p) {
     }                                                                                               \
   } while (0)
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.nkc * p.ntaps;
   SET_TAP();
-  STAGE(0);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) STAGE();
 
-  // fragment read offsets (bytes) inside a tile: row * 128 + ((2*ks + hi) ^ (row & 7)) * 16, row & 7 == lq & 7
-  const int a_frag = (wm * 64 + lq) * 128;
-  const int b_frag = A_BYTES + (wn * 64 + lq) * 128;
-  const int sw = lq & 7;
+  // fragment read offsets (bytes) inside a stage: row * 128 + ((2*ks + hi) ^ key(row)) * 16
+  const int a_frag = (wm * 32 * MI + lq) * 128;
+  const int b_frag = A_BYTES + (wn * 32 * NJ + lq) * 128;
+  const int sw = (lq >> 1) & 7;
 
+  int c_slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt has landed for every wave; everyone is done reading buffer cur^1
-    if (kt + 1 < nk) STAGE(cur ^ 1);
-    const char* base = smem + cur * BUF_BYTES;
+    // tile kt landed (this wave's share); later tiles may stay in flight
+    if (kt + STAGES - 2 < nk)
+      wait_vmcnt<(STAGES - 2) * LOADS>();
+    else
+      wait_vmcnt<0>();
+    // every wave's share landed, and everyone is done reading the slot that is refilled next
+    asm volatile("s_barrier" ::: "memory");
+    if (kt + STAGES - 1 < nk) STAGE();
+    const char* base = smem + c_slot * BUF_BYTES;
+    c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int co = ((2 * ks + hi) ^ sw) * 16;
-      typename T::vec8 xf[2], wf[2];
+      typename T::vec8 xf[MI], wf[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        xf[i] = *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
         wf[j] = *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * 4096 + co);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
+        xf[i] = *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);  // D[n][m]
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);  // D[n][m]
     }
   }
 #undef STAGE
@@ -205,44 +242,79 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const G2Params p) {
   const int cs_ld = bn_out + 8;  // halfs; (bn_out + 8) * 2 B is a multiple of 16
   u16* Cs = reinterpret_cast<u16*>(smem);
   const u16* __restrict__ RV = reinterpret_cast<const u16*>(d.rowvec);
-  __syncthreads();  // all waves finished reading the operand tiles
+
+  // bias for this lane's columns (independent of the row tile): [j][g] -> 4 consecutive columns
+  float4 b4[NJ][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wm * 64 + i * 32 + lq;
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n0 = tn * BN + wn * 32 * NJ + j * 32 + 8 * g + 4 * hi;
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d.bias) {
+        if (p.vec_bias && n0 + 4 <= N) {
+          b = *reinterpret_cast<const float4*>(d.bias + n0);
+        } else {
+          if (n0 + 0 < N) b.x = d.bias[n0 + 0];
+          if (n0 + 1 < N) b.y = d.bias[n0 + 1];
+          if (n0 + 2 < N) b.z = d.bias[n0 + 2];
+          if (n0 + 3 < N) b.w = d.bias[n0 + 3];
+        }
+      }
+      b4[j][g] = b;
+    }
+
+  __syncthreads();  // all waves finished reading the operand tiles (no glds in flight any more)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * 32 * MI + i * 32 + lq;
     const int m = tm * BM + row;
     const int mb = (m < M ? m : M - 1);
     const u16* rvp = RV ? RV + (long long)(mb / d.rows_per_batch) * d.rowvec_ld : nullptr;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (geglu && j == 1) continue;
+    for (int j = 0; j < NJ; ++j) {
+      if (geglu && (j & 1)) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nl = wn * 64 + j * 32 + 8 * g + 4 * hi;  // local packed column of element 0
+        const int nl = wn * 32 * NJ + j * 32 + 8 * g + 4 * hi;  // local packed column of element 0
         const int n0 = tn * BN + nl;
-        float v[4];
+        float v[4] = {acc[i][j][4 * g + 0] + b4[j][g].x, acc[i][j][4 * g + 1] + b4[j][g].y,
+                      acc[i][j][4 * g + 2] + b4[j][g].z, acc[i][j][4 * g + 3] + b4[j][g].w};
+        if (rvp) {
+          if (p.vec_rv && n0 + 4 <= N) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(rvp + n0);
+            v[0] += T::to_f32((u16)(rr.x & 0xffff));
+            v[1] += T::to_f32((u16)(rr.x >> 16));
+            v[2] += T::to_f32((u16)(rr.y & 0xffff));
+            v[3] += T::to_f32((u16)(rr.y >> 16));
+          } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + e;
-          float x = acc[i][j][4 * g + e];
-          if (d.bias && n < N) x += d.bias[n];
-          if (rvp && n < N) x += T::to_f32(rvp[n]);
-          if (d.act == DBIR_ACT_SILU) {
-            x = silu_f(x);
-          } else if (d.act == DBIR_ACT_GELU) {
-            x = gelu_f(x);
-          } else if (d.act == DBIR_ACT_LRELU) {
-            x = x > 0.f ? x : x * d.act_param;
-          } else if (geglu) {
-            float gte = acc[i][1][4 * g + e];
-            if (d.bias && n + 32 < N) gte += d.bias[n + 32];
-            x = x * gelu_f(gte);
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < N) v[e] += T::to_f32(rvp[n0 + e]);
           }
-          v[e] = x * d.out_scale;
         }
-        const int ocl = geglu ? (wn * 32 + 8 * g + 4 * hi) : nl;
+        if (d.act == DBIR_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        } else if (d.act == DBIR_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+        } else if (d.act == DBIR_ACT_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * d.act_param;
+        } else if (geglu) {
+          if constexpr (NJ >= 2) {
+            constexpr int JG = 1;  // gate tile of this value tile (NJ == 2: tiles are (value, gate))
+            const float gt[4] = {acc[i][JG][4 * g + 0] + b4[JG][g].x, acc[i][JG][4 * g + 1] + b4[JG][g].y,
+                                 acc[i][JG][4 * g + 2] + b4[JG][g].z, acc[i][JG][4 * g + 3] + b4[JG][g].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_fast(gt[e]);
+          }
+        }
+        const int ocl = geglu ? (wn * 16 * NJ + 8 * g + 4 * hi) : nl;
         uint2 pk;
-        pk.x = (uint32_t)T::from_f32(v[0]) | ((uint32_t)T::from_f32(v[1]) << 16);
-        pk.y = (uint32_t)T::from_f32(v[2]) | ((uint32_t)T::from_f32(v[3]) << 16);
+        pk.x = (uint32_t)T::from_f32(v[0] * d.out_scale) | ((uint32_t)T::from_f32(v[1] * d.out_scale) << 16);
+        pk.y = (uint32_t)T::from_f32(v[2] * d.out_scale) | ((uint32_t)T::from_f32(v[3] * d.out_scale) << 16);
         *reinterpret_cast<uint2*>(Cs + row * cs_ld + ocl) = pk;
       }
     }
@@ -254,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const G2Params p) {
     const int total = BM * ch_per_row;
     const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) + (long long)bz * d.strideR_z : nullptr;
     u16* __restrict__ Cg = reinterpret_cast<u16*>(d.C) + (long long)bz * d.strideC_z;
-    for (int q = tid; q < total; q += 256) {
+    for (int q = tid; q < total; q += NT) {
       const int row = q / ch_per_row, ch = q - row * ch_per_row;
       const int m = tm * BM + row;
       const int ncol = tn * bn_out + ch * 8;
@@ -287,20 +359,25 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const G2Params p) {
   }
 }
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES>
 int launch2(G2Params& p, hipStream_t s) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
+  constexpr int ring = STAGES * (BM + BN) * 128, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
+  constexpr int lds = ring > epi ? ring : epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  constexpr int blocks_per_cu = (160 * 1024) / lds;
+  constexpr int waves = WM * WN * (blocks_per_cu > 2 ? 2 : blocks_per_cu);
+  constexpr int MINW = waves >= 8 ? 2 : 1;
+  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, WM, WN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   p.mtiles = cdiv(p.d.M, BM);
   p.ntiles = cdiv(p.d.N, BN);
   dim3 grid((unsigned)(p.mtiles * p.ntiles), p.d.batch > 0 ? p.d.batch : 1);
-  hipLaunchKernelGGL((gemm_glds_kernel<T, WM, WN>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
   DBIR_CHECK_LAUNCH("dbir_gemm(glds)");
   return DBIR_OK;
 }
@@ -308,9 +385,14 @@ int launch2(G2Params& p, hipStream_t s) {
 template <typename T>
 int dispatch2(G2Params& p, int tile, hipStream_t s) {
   switch (tile) {
-    case 5: return launch2<T, 2, 2>(p, s);
-    case 6: return launch2<T, 4, 1>(p, s);
-    case 7: return launch2<T, 1, 4>(p, s);
+    case 5: return launch2<T, 2, 2, 2, 2, 2>(p, s);   // 128x128, 4 waves, 2 stages, 2 blocks / CU
+    case 6: return launch2<T, 4, 1, 2, 2, 2>(p, s);   // 256x64
+    case 7: return launch2<T, 1, 4, 2, 2, 2>(p, s);   // 64x256
+    case 8: return launch2<T, 2, 2, 4, 2, 3>(p, s);   // 256x128, 4 waves (128x64 each), 3 stages
+    case 9: return launch2<T, 4, 2, 2, 2, 3>(p, s);   // 256x128, 8 waves (64x64 each), 3 stages
+    case 10: return launch2<T, 2, 4, 4, 2, 2>(p, s);  // 256x256, 8 waves (128x64 each), 2 stages
+    case 11: return launch2<T, 2, 2, 2, 2, 4>(p, s);  // 128x128, 4 waves, 4 stages, 1 block / CU
+    case 12: return launch2<T, 4, 2, 2, 2, 2>(p, s);  // 256x128, 8 waves, 2 stages
   }
   dbir_set_error("dbir_gemm: bad glds tile %d", tile);
   return DBIR_ERR_ARG;
@@ -347,10 +429,22 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
     p.nkc = dd.Cin / BK;
     p.ntaps = 9;
   }
+  p.vec_bias = dd.bias && (reinterpret_cast<uintptr_t>(dd.bias) & 15) == 0;
+  p.vec_rv = dd.rowvec && (reinterpret_cast<uintptr_t>(dd.rowvec) & 7) == 0 && dd.rowvec_ld % 4 == 0;
   if (tile == 0) {
-    // N = 320 (the 64x64-latent level of the UNet) tiles exactly with 64-wide column tiles; otherwise 128x128.
-    const int waste128 = cdiv(dd.N, 128) * 128 - dd.N, waste64 = cdiv(dd.N, 64) * 64 - dd.N;
-    tile = (dd.act != DBIR_ACT_GEGLU && waste64 < waste128 && dd.M >= 2048) ? 6 : 5;
+    // Tile choice from the MI355X microbenchmarks (tools/bench_kernels.py, profiles/kbench_r1.json):
+    //   256x256 (tile 10, 128x64 per wave: fewest LDS reads per MFMA) whenever N wastes <= 20 % of 256-wide column
+    //   tiles and there are enough tiles to occupy the 256 CUs; 256x128 (tile 12) for large M otherwise;
+    //   128x128 at 2 blocks / CU (tile 5) for the small-M (8x8 latent level, text context) problems.
+    const int nt256 = cdiv(dd.N, 256);
+    const bool fits256 = (nt256 * 256 - dd.N) * 5 <= nt256 * 256;
+    const long long blocks256 = (long long)cdiv(dd.M, 256) * nt256 * (dd.batch > 0 ? dd.batch : 1);
+    if (dd.act == DBIR_ACT_GEGLU || (fits256 && blocks256 >= 150))
+      tile = 10;
+    else if (dd.M >= 4096)
+      tile = 12;
+    else
+      tile = 5;
   }
   return dd.dtype == DBIR_F16 ? dispatch2<F16>(p, tile, s) : dispatch2<BF16>(p, tile, s);
 }

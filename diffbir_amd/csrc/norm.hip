@@ -4,18 +4,18 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// GroupNorm, three launches:
-//  1. gn_partial : grid (nchunk, B). Thread owns one 8-channel vector (16 B loads, coalesced along C) and walks
-//                  the chunk's rows; per-channel (sum, sumsq) combined through LDS in a fixed order
-//                  -> partial[b][chunk][2C] (deterministic: no float atomics anywhere).
-//  2. gn_finalize: grid (B). Sums the chunks, reduces channels -> groups, emits per-(b,c) affine coefficients
-//                  a = rstd*gamma, s = beta - mean*rstd*gamma.
-//  3. gn_apply   : y = act(x*a + s), vectorised elementwise.
+// GroupNorm, two launches, deterministic (no float atomics: bit-reproducible and batch-size independent):
+//  1. gn_stats: grid (nchunk, B). Thread owns one 8-channel vector (16 B loads, coalesced along C) and walks
+//               the chunk's rows; per-channel (sum, sumsq) are combined through LDS in a fixed order, then reduced
+//               channels -> groups -> partial[b][chunk][2*groups].
+//  2. gn_apply: grid (nblk, B). Every block first sums the nchunk partials of its sample in a fixed order
+//               (<= 64 x 64 floats, L2 resident) -> mean / rstd per group in LDS, folds them with gamma / beta into
+//               per-thread coefficients, then streams y = act(x*a + s).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void gn_partial(const u16* __restrict__ x, long long ldx, float* __restrict__ partial, int HW, int C,
-                           int rows_per_chunk, int rpi) {
-  extern __shared__ float sh[];  // [rpi][2*C]: per row-subset partial sums, combined in a FIXED order below
+__global__ void gn_stats(const u16* __restrict__ x, long long ldx, float* __restrict__ partial, int HW, int C,
+                         int groups, int rows_per_chunk, int rpi) {
+  extern __shared__ float sh[];  // [rpi][2*C] per row-subset partial sums, then [2*C] per-channel sums
   const int CV = C >> 3;
   const int t = threadIdx.x;
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -26,7 +26,23 @@ __global__ void gn_partial(const u16* __restrict__ x, long long ldx, float* __re
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
   const u16* xb = x + (long long)b * HW * ldx + cv * 8;
-  for (int r = r_begin + rsub; r < r_end; r += rpi) {
+  int r = r_begin + rsub;
+  for (; r + 3 * rpi < r_end; r += 4 * rpi) {  // 4 independent 16-byte loads in flight per thread
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(xb + (long long)(r + u * rpi) * ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[8];
+      unpack8<T>(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[e] += f[e];
+        ss[e] += f[e] * f[e];
+      }
+    }
+  }
+  for (; r < r_end; r += rpi) {
     const uint4 v = *reinterpret_cast<const uint4*>(xb + (long long)r * ldx);
     float f[8];
     unpack8<T>(v, f);
@@ -43,130 +59,155 @@ __global__ void gn_partial(const u16* __restrict__ x, long long ldx, float* __re
     mine[C + cv * 8 + e] = ss[e];
   }
   __syncthreads();
-  // deterministic combine (no float atomics: results are bit-reproducible run to run and batch-size independent)
-  float* out = partial + ((long long)b * gridDim.x + chunk) * 2 * C;
   for (int i = t; i < 2 * C; i += blockDim.x) {
     float a = 0.f;
     for (int k = 0; k < rpi; ++k) a += sh[(long long)k * 2 * C + i];
-    out[i] = a;
+    sh[i] = a;  // row-subset 0's slot: only this thread reads column i of the other subsets
   }
-}
-
-__global__ void gn_finalize(const float* __restrict__ partial, const float* __restrict__ gamma,
-                            const float* __restrict__ beta, float* __restrict__ coef, int nchunk, int HW, int C,
-                            int groups, float eps) {
-  extern __shared__ float sh[];  // [2*C] per-channel sums, then [2*groups] mean / rstd
-  const int b = blockIdx.x, t = threadIdx.x;
+  __syncthreads();
   const int cpg = C / groups;
-  const float* pb = partial + (long long)b * nchunk * 2 * C;
-  for (int c = t; c < 2 * C; c += blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += pb[(long long)k * 2 * C + c];
-    sh[c] = s;
-  }
-  __syncthreads();
-  float* stat = sh + 2 * C;
-  if (t < groups) {
-    float s = 0.f, ss = 0.f;
-    for (int c = t * cpg; c < (t + 1) * cpg; ++c) {
-      s += sh[c];
-      ss += sh[C + c];
-    }
-    const float n = (float)HW * (float)cpg;
-    const float mean = s / n;
-    const float var = fmaxf(ss / n - mean * mean, 0.f);
-    stat[t] = mean;
-    stat[groups + t] = rsqrtf(var + eps);
-  }
-  __syncthreads();
-  float* cb = coef + (long long)b * 2 * C;
-  for (int c = t; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float a = stat[groups + g] * gamma[c];
-    cb[c] = a;
-    cb[C + c] = beta[c] - stat[g] * a;
+  float* out = partial + ((long long)b * gridDim.x + chunk) * 2 * groups;
+  for (int g = t; g < 2 * groups; g += blockDim.x) {
+    const int base = g < groups ? g * cpg : C + (g - groups) * cpg;
+    float a = 0.f;
+    for (int c = 0; c < cpg; ++c) a += sh[base + c];
+    out[g] = a;
   }
 }
 
 template <typename T>
 __global__ void gn_apply(const u16* __restrict__ x, long long ldx, u16* __restrict__ y, long long ldy,
-                         const float* __restrict__ coef, int HW, int C, long long total_vec, int silu) {
+                         const float* __restrict__ partial, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, int nchunk, int HW, int C, int groups, float eps,
+                         int rows_per_blk, int rpi, int silu) {
+  __shared__ float stat[128];  // mean[groups], rstd[groups]
   const int CV = C >> 3;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long row = i / CV;
-    const int cv = (int)(i - row * CV);
-    const int b = (int)(row / HW);
-    const uint4 v = *reinterpret_cast<const uint4*>(x + row * ldx + cv * 8);
+  const int t = threadIdx.x;
+  const int b = blockIdx.y;
+  const int cpg = C / groups;
+  if (t < 2 * groups) {
+    const float* pb = partial + (long long)b * nchunk * 2 * groups + t;
+    float a = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < nchunk; ++k) a += pb[(long long)k * 2 * groups];
+    stat[t] = a;
+  }
+  __syncthreads();
+  float mean = 0.f, rstd = 0.f;
+  if (t < groups) {
+    const float n = (float)HW * (float)cpg;
+    mean = stat[t] / n;
+    const float var = fmaxf(stat[groups + t] / n - mean * mean, 0.f);
+    rstd = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  if (t < groups) {
+    stat[t] = mean;
+    stat[groups + t] = rstd;
+  }
+  __syncthreads();
+  const int cv = t % CV, rsub = t / CV;
+  float av[8], sv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cv * 8 + e;
+    const int g = c / cpg;
+    const float a = stat[groups + g] * gamma[c];
+    av[e] = a;
+    sv[e] = beta[c] - stat[g] * a;
+  }
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(HW, r_begin + rows_per_blk);
+  const u16* xb = x + (long long)b * HW * ldx + cv * 8;
+  u16* yb = y + (long long)b * HW * ldy + cv * 8;
+  for (int r = r_begin + rsub; r < r_end; r += rpi) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xb + (long long)r * ldx);
     float f[8];
     unpack8<T>(v, f);
-    const float* ca = coef + (long long)b * 2 * C + cv * 8;
-    const float4 a0 = *reinterpret_cast<const float4*>(ca), a1 = *reinterpret_cast<const float4*>(ca + 4);
-    const float4 s0 = *reinterpret_cast<const float4*>(ca + C), s1 = *reinterpret_cast<const float4*>(ca + C + 4);
-    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float o = f[e] * av[e] + sv[e];
+      const float o = f[e] * av[e] + sv[e];
       f[e] = silu ? silu_f(o) : o;
     }
-    *reinterpret_cast<uint4*>(y + row * ldy + cv * 8) = pack8<T>(f);
+    *reinterpret_cast<uint4*>(yb + (long long)r * ldy) = pack8<T>(f);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm: one wave64 per row, row held in registers (two-pass statistics, f32).
+// LayerNorm: one wave64 per group of RW rows (RW independent load -> reduce -> normalise chains in flight per
+// wave: the kernel is latency-bound otherwise), rows held in registers, two-pass statistics in f32.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MAXV>
+template <typename T, int MAXV, int RW>
 __global__ __launch_bounds__(256) void ln_kernel(const u16* __restrict__ x, long long ldx, u16* __restrict__ y,
                                                  long long ldy, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, int rows, int C, int Cpad,
                                                  float eps) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= rows) return;
   const int NV = Cpad >> 3;
-  float f[MAXV][8];
-  float sum = 0.f;
+  float f[RW][MAXV][8];
+  float sum[RW];
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int v = lane + 64 * k;
-    if (v < NV) {
-      const uint4 q = *reinterpret_cast<const uint4*>(x + row * ldx + v * 8);
-      unpack8<T>(q, f[k]);
+  for (int r = 0; r < RW; ++r) {
+    sum[r] = 0.f;
+    const long long row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int v = lane + 64 * k;
+      if (v < NV) {
+        const uint4 q = *reinterpret_cast<const uint4*>(x + row * ldx + v * 8);
+        unpack8<T>(q, f[r][k]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (v * 8 + e >= C) f[r][k][e] = 0.f;
+          sum[r] += f[r][k][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[r][k][e] = 0.f;
+      }
+    }
+  }
+  float mean[RW], rstd[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) mean[r] = wave_sum(sum[r]) / (float)C;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int v = lane + 64 * k;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        if (v * 8 + e >= C) f[k][e] = 0.f;
-        sum += f[k][e];
+        const float dlt = (v * 8 + e < C) ? f[r][k][e] - mean[r] : 0.f;
+        sq += dlt * dlt;
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[k][e] = 0.f;
     }
+    sum[r] = sq;
   }
-  const float mean = wave_sum(sum) / (float)C;
-  float sq = 0.f;
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int v = lane + 64 * k;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float dlt = (v * 8 + e < C) ? f[k][e] - mean : 0.f;
-      sq += dlt * dlt;
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  for (int r = 0; r < RW; ++r) rstd[r] = rsqrtf(wave_sum(sum[r]) / (float)C + eps);
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int v = lane + 64 * k;
     if (v < NV) {
-      float o[8];
+      float gm[8], bt[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = v * 8 + e;
-        o[e] = c < C ? (f[k][e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+        gm[e] = c < C ? gamma[c] : 0.f;
+        bt[e] = c < C ? beta[c] : 0.f;
       }
-      *reinterpret_cast<uint4*>(y + row * ldy + v * 8) = pack8<T>(o);
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        if (row0 + r < rows) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (v * 8 + e < C) ? (f[r][k][e] - mean[r]) * rstd[r] * gm[e] + bt[e] : 0.f;
+          *reinterpret_cast<uint4*>(y + (row0 + r) * ldy + v * 8) = pack8<T>(o);
+        }
+      }
     }
   }
 }
@@ -233,37 +274,40 @@ extern "C" int dbir_groupnorm(int dtype, const void* x, long long ldx, void* y, 
   DBIR_CHECK_ARG(x && y && gamma && beta && workspace, "dbir_groupnorm: null pointer");
   DBIR_CHECK_ARG(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 4096,
                  "dbir_groupnorm: need C%%8==0, C%%groups==0, ld%%8==0 (C=%d)", C);
-  DBIR_CHECK_ARG(groups <= 64, "dbir_groupnorm: groups must be <= 64");
+  DBIR_CHECK_ARG(groups <= 64 && B > 0 && B <= 65535, "dbir_groupnorm: groups must be <= 64, B <= 65535");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nchunk = dbir_groupnorm_nchunk(HW, C);
+  // ~512 blocks per launch (2 per CU), never more chunks than the workspace contract (dbir_groupnorm_nchunk)
+  int nchunk = (512 + B - 1) / B;
+  const int cap = dbir_groupnorm_nchunk(HW, C);
+  if (nchunk > cap) nchunk = cap;
   const int rows_per_chunk = (HW + nchunk - 1) / nchunk;
+  nchunk = (HW + rows_per_chunk - 1) / rows_per_chunk;
   const int CV = C / 8;
   const int rpi = CV >= 256 ? 1 : 256 / CV;
   const int threads = CV * rpi;
-  DBIR_CHECK_ARG(threads <= 1024, "dbir_groupnorm: C too large");
-  float* partial = workspace;
-  float* coef = workspace + (long long)B * nchunk * 2 * C;
+  DBIR_CHECK_ARG(threads <= 1024 && threads >= 2 * groups, "dbir_groupnorm: unsupported C / groups combination");
+  float* partial = workspace;  // [B][nchunk][2*groups]
   const size_t sh1 = (size_t)rpi * 2 * C * sizeof(float);
-  const long long total_vec = (long long)B * HW * CV;
-  const int ablocks = (int)((total_vec + 255) / 256 > 4096 ? 4096 : (total_vec + 255) / 256);
-  if (dtype == DBIR_F16) {
-    hipLaunchKernelGGL((gn_partial<F16>), dim3(nchunk, B), dim3(threads), sh1, s, (const u16*)x, ldx, partial, HW, C,
-                       rows_per_chunk, rpi);
-  } else if (dtype == DBIR_BF16) {
-    hipLaunchKernelGGL((gn_partial<BF16>), dim3(nchunk, B), dim3(threads), sh1, s, (const u16*)x, ldx, partial, HW,
-                       C, rows_per_chunk, rpi);
-  } else {
+  int nblk = (1024 + B - 1) / B;
+  int rows_per_blk = (HW + nblk - 1) / nblk;
+  if (rows_per_blk < rpi) rows_per_blk = rpi;
+  nblk = (HW + rows_per_blk - 1) / rows_per_blk;
+#define GN_LAUNCH(TT)                                                                                              \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((gn_stats<TT>), dim3(nchunk, B), dim3(threads), sh1, s, (const u16*)x, ldx, partial, HW, C,  \
+                       groups, rows_per_chunk, rpi);                                                               \
+    hipLaunchKernelGGL((gn_apply<TT>), dim3(nblk, B), dim3(threads), 0, s, (const u16*)x, ldx, (u16*)y, ldy,       \
+                       partial, gamma, beta, nchunk, HW, C, groups, eps, rows_per_blk, rpi, silu);                  \
+  } while (0)
+  if (dtype == DBIR_F16)
+    GN_LAUNCH(F16);
+  else if (dtype == DBIR_BF16)
+    GN_LAUNCH(BF16);
+  else {
     dbir_set_error("dbir_groupnorm: bad dtype");
     return DBIR_ERR_ARG;
   }
-  hipLaunchKernelGGL(gn_finalize, dim3(B), dim3(256), (size_t)(2 * C + 2 * groups) * sizeof(float), s, partial, gamma, beta, coef,
-                     nchunk, HW, C, groups, eps);
-  if (dtype == DBIR_F16)
-    hipLaunchKernelGGL((gn_apply<F16>), dim3(ablocks), dim3(256), 0, s, (const u16*)x, ldx, (u16*)y, ldy, coef, HW,
-                       C, total_vec, silu);
-  else
-    hipLaunchKernelGGL((gn_apply<BF16>), dim3(ablocks), dim3(256), 0, s, (const u16*)x, ldx, (u16*)y, ldy, coef,
-                       HW, C, total_vec, silu);
+#undef GN_LAUNCH
   DBIR_CHECK_LAUNCH("dbir_groupnorm");
   return DBIR_OK;
 }
@@ -274,20 +318,20 @@ extern "C" int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, 
   DBIR_CHECK_ARG(Cpad % 8 == 0 && Cpad >= C && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= Cpad && ldy >= Cpad,
                  "dbir_layernorm: bad C/Cpad/ld");
   DBIR_CHECK_ARG(Cpad <= 64 * 8 * 4, "dbir_layernorm: C up to 2048 supported (got %d)", Cpad);
+  DBIR_CHECK_ARG(rows > 0, "dbir_layernorm: bad rows");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int blocks = (rows + 3) / 4;
   const int nv = Cpad / 8;
-#define LN_LAUNCH(TT, MV)                                                                                         \
-  hipLaunchKernelGGL((ln_kernel<TT, MV>), dim3(blocks), dim3(256), 0, s, (const u16*)x, ldx, (u16*)y, ldy, gamma, \
-                     beta, rows, C, Cpad, eps)
+#define LN_LAUNCH(TT, MV, RW)                                                                                     \
+  hipLaunchKernelGGL((ln_kernel<TT, MV, RW>), dim3((rows + 4 * RW - 1) / (4 * RW)), dim3(256), 0, s, (const u16*)x, \
+                     ldx, (u16*)y, ldy, gamma, beta, rows, C, Cpad, eps)
   if (dtype == DBIR_F16) {
-    if (nv <= 64) LN_LAUNCH(F16, 1);
-    else if (nv <= 128) LN_LAUNCH(F16, 2);
-    else LN_LAUNCH(F16, 4);
+    if (nv <= 64) LN_LAUNCH(F16, 1, 4);
+    else if (nv <= 128) LN_LAUNCH(F16, 2, 2);
+    else LN_LAUNCH(F16, 4, 1);
   } else if (dtype == DBIR_BF16) {
-    if (nv <= 64) LN_LAUNCH(BF16, 1);
-    else if (nv <= 128) LN_LAUNCH(BF16, 2);
-    else LN_LAUNCH(BF16, 4);
+    if (nv <= 64) LN_LAUNCH(BF16, 1, 4);
+    else if (nv <= 128) LN_LAUNCH(BF16, 2, 2);
+    else LN_LAUNCH(BF16, 4, 1);
   } else {
     dbir_set_error("dbir_layernorm: bad dtype");
     return DBIR_ERR_ARG;

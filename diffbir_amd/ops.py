@@ -154,8 +154,8 @@ def stop_profile():
 class _Timed:
     """Brackets ONE kernel launch with HIP events on the current stream when profiling is on (else free)."""
 
-    def __init__(self, kind: str, flops: float):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind: str, flops: float, tag: str = ""):
+        self.kind, self.flops, self.tag = kind, flops, tag
 
     def __enter__(self):
         if _PROFILE is not None:
@@ -167,12 +167,17 @@ class _Timed:
     def __exit__(self, *a):
         if _PROFILE is not None:
             self.e1.record()
-            _PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+            _PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag))
         return False
 
 
 def _gemm_launch(d: GemmDesc, keep):
-    with _Timed("gemm", 2.0 * d.M * (d.N) * d.K * max(d.batch, 1)):
+    tag = ""
+    if _PROFILE is not None:
+        tag = (f"{'conv' if d.mode == MODE_CONV3X3 else 'lin'} M{d.M} N{d.N} K{d.K} z{max(d.batch, 1)} act{d.act}"
+               f"{' s2' if d.stride == 2 else ''}{' up' if d.upsample else ''}{' T' if d.store_mode else ''}"
+               f"{' f32' if d.out_f32 else ''}{' res' if d.R else ''}")
+    with _Timed("gemm", 2.0 * d.M * (d.N) * d.K * max(d.batch, 1), tag):
         native.check(native.lib().dbir_gemm(ctypes.byref(d), _stream()), "dbir_gemm")
 
 
@@ -285,7 +290,7 @@ def attention(q: T, k: T, vt: T, out: T, heads: int, Lk: int, scale: float) -> T
     _gpu(q, k, vt, out)
     B, Lq = q.shape[0], q.shape[1]
     assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1 and out.stride(2) == 1
-    with _Timed("attention", 4.0 * B * heads * Lq * Lk * 64):
+    with _Timed("attention", 4.0 * B * heads * Lq * Lk * 64, f"attn B{B} H{heads} Lq{Lq} Lk{Lk}"):
         native.check(native.lib().dbir_attention(
             _dt(q), q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
             vt.data_ptr(), vt.stride(0), vt.stride(1), out.data_ptr(), out.stride(0), out.stride(1),

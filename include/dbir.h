@@ -83,7 +83,8 @@ typedef struct dbir_gemm_desc {
   long long trans_ld, trans_bstride;
   int batch;
   int tile; /* 0 = auto; generic kernel 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64; direct-to-LDS kernel 5: 128x128,
-               6: 256x64, 7: 64x256 (testing / tuning) */
+               6: 256x64, 7: 64x256, 8/9: 256x128 (4 / 8 waves, 3-stage ring), 10: 256x256, 11: 128x128 4-stage,
+               12: 256x128 2-stage (testing / tuning) */
 } dbir_gemm_desc;
 int dbir_gemm(const dbir_gemm_desc* d, void* stream);
 

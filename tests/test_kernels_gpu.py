@@ -187,7 +187,7 @@ def test_conv3x3_fused_epilogue(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
-GLDS_TILES = [5, 6, 7]
+GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
