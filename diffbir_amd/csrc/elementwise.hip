@@ -168,6 +168,33 @@ __global__ void tile_accumulate_kernel(const float* __restrict__ tiles, const fl
   }
 }
 
+// Sharded form of tile_accumulate_kernel: un-normalised weighted sum over a SUBSET of tiles (tiles == nullptr: the
+// weights alone, i.e. the normaliser, which depends on the window coordinates only).
+__global__ void tile_accumulate_partial_kernel(const float* __restrict__ tiles, const float* __restrict__ weights,
+                                               const int* __restrict__ coords, float* __restrict__ num, int T, int B,
+                                               int C, int H, int W, int ts) {
+  GRID_STRIDE(i, (long long)B * C * H * W) {
+    const int xx = (int)(i % W);
+    const int yy = (int)((i / W) % H);
+    const long long bc = i / ((long long)W * H);
+    const int c = (int)(bc % C), b = (int)(bc / C);
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const int ly = yy - coords[2 * t], lx = xx - coords[2 * t + 1];
+      if (ly >= 0 && ly < ts && lx >= 0 && lx < ts) {
+        const float w = weights[ly * ts + lx];
+        acc += tiles ? tiles[((((long long)t * B + b) * C + c) * ts + ly) * ts + lx] * w : w;
+      }
+    }
+    num[i] = acc;
+  }
+}
+
+__global__ void tile_normalize_kernel(const float* __restrict__ num, const float* __restrict__ den,
+                                      float* __restrict__ out, long long BC, long long HW) {
+  GRID_STRIDE(i, BC * HW) { out[i] = num[i] / den[i % HW]; }
+}
+
 __global__ void u8_to_f32_nchw_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int B,
                                       long long HW) {
   GRID_STRIDE(i, (long long)B * 3 * HW) {
@@ -316,6 +343,23 @@ extern "C" int dbir_tile_accumulate(const float* tiles, const float* weights, co
   hipLaunchKernelGGL(tile_accumulate_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(TPB), 0, STREAM, tiles,
                      weights, coords, out, T, B, C, H, W, ts);
   DBIR_CHECK_LAUNCH("dbir_tile_accumulate");
+  return DBIR_OK;
+}
+
+extern "C" int dbir_tile_accumulate_partial(const float* tiles, const float* weights, const int* coords, float* num,
+                                            int T, int B, int C, int H, int W, int ts, void* stream) {
+  DBIR_CHECK_ARG(weights && coords && num && T > 0, "dbir_tile_accumulate_partial: bad args");
+  hipLaunchKernelGGL(tile_accumulate_partial_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(TPB), 0, STREAM,
+                     tiles, weights, coords, num, T, B, C, H, W, ts);
+  DBIR_CHECK_LAUNCH("dbir_tile_accumulate_partial");
+  return DBIR_OK;
+}
+
+extern "C" int dbir_tile_normalize(const float* num, const float* den, float* out, long long BC, long long HW,
+                                   void* stream) {
+  DBIR_CHECK_ARG(num && den && out && BC > 0 && HW > 0, "dbir_tile_normalize: bad args");
+  hipLaunchKernelGGL(tile_normalize_kernel, dim3(grid_for(BC * HW)), dim3(TPB), 0, STREAM, num, den, out, BC, HW);
+  DBIR_CHECK_LAUNCH("dbir_tile_normalize");
   return DBIR_OK;
 }
 

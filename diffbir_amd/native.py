@@ -55,6 +55,8 @@ SIGNATURES = {
     "dbir_spaced_step": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _LL, _P],
     "dbir_tile_gather": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dbir_tile_accumulate": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dbir_tile_accumulate_partial": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dbir_tile_normalize": [_P, _P, _P, _LL, _LL, _P],
     "dbir_u8_to_f32_nchw": [_P, _P, _I, _I, _I, _P],
     "dbir_wavelet_blur": [_P, _P, _I, _I, _I, _I, _P],
     "dbir_colorfix": [_P, _P, _P, _P, _LL, _P],

@@ -450,6 +450,32 @@ def tile_accumulate(tiles: T, weights: T, coords: T, B: int, H: int, W: int) -> 
     return out
 
 
+def tile_accumulate_partial(tiles: Optional[T], weights: T, coords: T, B: int, C: int, H: int, W: int) -> T:
+    """Un-normalised weighted sum over the tiles given (a rank's shard); tiles=None -> the normaliser (B=C=1)."""
+    _gpu(tiles, weights, coords)
+    assert weights.dtype == torch.float32 and coords.dtype == torch.int32 and coords.is_contiguous()
+    Tn, ts = coords.shape[0], weights.shape[-1]
+    if tiles is not None:
+        assert tiles.dtype == torch.float32 and tiles.is_contiguous() and tuple(tiles.shape) == (Tn * B, C, ts, ts)
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=weights.device)
+    native.check(native.lib().dbir_tile_accumulate_partial(None if tiles is None else tiles.data_ptr(),
+                                                           weights.data_ptr(), coords.data_ptr(), out.data_ptr(), Tn,
+                                                           B, C, H, W, ts, _stream()), "dbir_tile_accumulate_partial")
+    return out
+
+
+def tile_normalize(num: T, den: T) -> T:
+    """out[b,c] = num[b,c] / den  (den: f32 [H,W] or [1,1,H,W])."""
+    _gpu(num, den)
+    assert num.dtype == torch.float32 and num.is_contiguous() and den.is_contiguous() and den.dtype == torch.float32
+    H, W = num.shape[-2:]
+    assert den.numel() == H * W
+    out = torch.empty_like(num)
+    native.check(native.lib().dbir_tile_normalize(num.data_ptr(), den.data_ptr(), out.data_ptr(),
+                                                  num.numel() // (H * W), H * W, _stream()), "dbir_tile_normalize")
+    return out
+
+
 def u8_to_f32_nchw(src: T) -> T:
     _gpu(src)
     assert src.dtype == torch.uint8 and src.is_contiguous() and src.shape[-1] == 3

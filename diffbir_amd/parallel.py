@@ -1,0 +1,184 @@
+"""Multi-GPU execution of the restoration pipeline: one process per GPU, `torch.distributed` (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" on CPU for the tests).  SURVEY.md §8(e).
+
+The reference is single-device (its only multi-GPU mechanism is `accelerate` in the training scripts); the hot path
+shards naturally because every stage is per-sample (GroupNorm / LayerNorm are per-sample, no BatchNorm):
+
+  * **batch sharding** (`run_data_parallel`): rank r restores the contiguous slice `shard_range(B, r, world)` of the
+    batch.  No collective inside the sampling loop.  Weights: every rank loads / generates the same state dict, or
+    rank 0 does and `broadcast_state_dict` ships it (RCCL broadcast, bucketed flat buffers).  Outputs: uint8
+    [b_r, H, W, 3] slices are gathered to rank 0 (`gather_batch`; ragged slices are padded to the largest).
+  * **noise parity**: the reference draws `x_T = randn((B,4,h,w))` and one `randn_like(x)` per step for the WHOLE batch
+    on one generator (pipeline.py:159, spaced_sampler.py:181).  `ShardedNoise` makes every rank draw the full-batch
+    tensor from an identically seeded generator, in the same order, and keep its rows — the restored images do not
+    depend on the number of GPUs (64 KB per sample per step: cheaper than a broadcast).
+  * **tile sharding** (`enable_tile_sharding`) for tiled sampling of large images: the T tiles of one network
+    evaluation are split round-robin over the ranks and the partial weighted sums are combined with ONE all-reduce
+    per evaluation (`diffbir_amd.utils.tiling.TiledModel`); every rank then performs the (cheap, deterministic given
+    the same noise) sampler update redundantly, so no broadcast of x is needed.
+
+Nothing here touches the kernels' C ABI: collectives are issued from Python on torch tensors.
+"""
+import os
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class DistContext:
+    rank: int = 0
+    world: int = 1
+    device: torch.device = torch.device("cpu")
+    group: Optional[object] = None
+
+    @property
+    def is_main(self) -> bool:
+        return self.rank == 0
+
+
+def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None) -> DistContext:
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun).
+    backend None -> "nccl" (RCCL) when a GPU is visible, else "gloo".  world == 1 needs no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device is None:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            device = torch.device("cuda", local)
+        else:
+            device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        be = backend or ("nccl" if device.type == "cuda" else "gloo")
+        kw = dict(device_id=device) if be == "nccl" else {}
+        dist.init_process_group(be, rank=rank, world_size=world, **kw)
+    return DistContext(rank, world, device)
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of n items for `rank` (the first n % world ranks get one extra)."""
+    per, extra = divmod(n, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+class ShardedNoise:
+    """Full-batch Gaussian draws (reference order) -> this rank's batch rows.
+
+    `base(shape)` must return identical values on every rank (an identically seeded torch.Generator, e.g.
+    oracle.cases.NoiseStream in tests or `seeded(seed, device)` below).  A requested shape [b_r, ...] whose leading
+    dim equals this rank's slice length is drawn as [B, ...] and sliced; any other shape passes through."""
+
+    def __init__(self, base: Callable, batch: int, lo: int, hi: int):
+        self.base, self.batch, self.lo, self.hi = base, batch, lo, hi
+
+    def __call__(self, shape) -> torch.Tensor:
+        shape = tuple(shape)
+        if len(shape) >= 1 and shape[0] == self.hi - self.lo:
+            return self.base((self.batch,) + shape[1:])[self.lo:self.hi].contiguous()
+        return self.base(shape)
+
+    @staticmethod
+    def seeded(seed: int, device) -> Callable:
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        return lambda shape: torch.randn(tuple(shape), generator=g, dtype=torch.float32, device=device)
+
+
+def all_reduce_sum(ctx: DistContext) -> Callable:
+    """tensor -> tensor summed over ranks (in place; RCCL all-reduce on the tensor's device)."""
+
+    def fn(t: torch.Tensor) -> torch.Tensor:
+        if ctx.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=ctx.group)
+        return t
+
+    return fn
+
+
+def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], spec, ctx: DistContext, src: int = 0,
+                         bucket_bytes: int = 256 << 20) -> Dict[str, torch.Tensor]:
+    """Ship a state dict from `src` to every rank.  `spec`: the module's OrderedDict key -> (shape, kind)
+    (model/specs.py) so receivers know names / shapes without a handshake.  Tensors travel as f32 in flat buckets of
+    `bucket_bytes` (few large RCCL broadcasts instead of ~3000 small ones: xGMI links are point-to-point, per-message
+    latency dominates small transfers)."""
+    if ctx.world == 1:
+        return sd
+    keys = [k for k, (_, kind) in spec.items() if kind != "buf"]
+    out: Dict[str, torch.Tensor] = {}
+    i = 0
+    while i < len(keys):
+        j, n = i, 0
+        while j < len(keys) and (n == 0 or (n + int(np.prod(spec[keys[j]][0]))) * 4 <= bucket_bytes):
+            n += int(np.prod(spec[keys[j]][0]))
+            j += 1
+        flat = torch.empty(n, dtype=torch.float32, device=ctx.device)
+        if ctx.rank == src:
+            off = 0
+            for k in keys[i:j]:
+                m = int(np.prod(spec[k][0]))
+                flat[off:off + m] = sd[k].reshape(-1).to(device=ctx.device, dtype=torch.float32)
+                off += m
+        dist.broadcast(flat, src=src, group=ctx.group)
+        off = 0
+        for k in keys[i:j]:
+            m = int(np.prod(spec[k][0]))
+            out[k] = flat[off:off + m].reshape(tuple(spec[k][0])).clone()
+            off += m
+        i = j
+    return out
+
+
+def gather_batch(local: np.ndarray, batch: int, ctx: DistContext, dst: int = 0) -> Optional[np.ndarray]:
+    """uint8 [b_r, H, W, 3] slices -> [B, H, W, 3] on rank `dst` (None elsewhere)."""
+    if ctx.world == 1:
+        return local
+    bmax = shard_range(batch, 0, ctx.world)
+    bmax = bmax[1] - bmax[0]
+    t = torch.zeros((bmax,) + local.shape[1:], dtype=torch.uint8, device=ctx.device)
+    t[: local.shape[0]] = torch.as_tensor(local).to(ctx.device)
+    bufs = [torch.empty_like(t) for _ in range(ctx.world)] if ctx.rank == dst else None
+    dist.gather(t, bufs, dst=dst, group=ctx.group)
+    if ctx.rank != dst:
+        return None
+    parts = []
+    for r, b in enumerate(bufs):
+        lo, hi = shard_range(batch, r, ctx.world)
+        parts.append(b[: hi - lo].cpu().numpy())
+    return np.concatenate(parts, axis=0)
+
+
+def enable_tile_sharding(pipe, ctx: DistContext) -> None:
+    """Tiled sampling evaluates tiles rank::world on this rank and all-reduces the partial sums."""
+    pipe.tile_shard = (ctx.rank, ctx.world) if ctx.world > 1 else None
+    pipe.tile_all_reduce = all_reduce_sum(ctx) if ctx.world > 1 else None
+
+
+def run_data_parallel(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise: Optional[Callable] = None,
+                      gather: bool = True) -> Optional[np.ndarray]:
+    """`pipe.run(lq, *run_args)` with the batch dimension of `lq` sharded over the ranks.
+
+    lq: the FULL uint8 batch [B,H,W,3] on every rank (or only meaningful on this rank's rows).  `noise`: full-batch
+    noise source shared by all ranks (identically seeded); None -> a device generator seeded with 231 (the
+    reference's default seed).  Returns the full restored batch on rank 0 (None on other ranks) when `gather`, else
+    this rank's slice."""
+    B = lq.shape[0]
+    lo, hi = shard_range(B, ctx.rank, ctx.world)
+    base = noise if noise is not None else ShardedNoise.seeded(231, ctx.device)
+    prev = pipe.randn
+    pipe.randn = ShardedNoise(base, B, lo, hi) if ctx.world > 1 else base
+    try:
+        if hi > lo:
+            out = pipe.run(lq[lo:hi], *run_args)
+        else:  # more ranks than images
+            out = np.zeros((0,) + tuple(lq.shape[1:]), dtype=np.uint8)
+    finally:
+        pipe.randn = prev
+    if not gather:
+        return out
+    return gather_batch(out, B, ctx)

@@ -51,6 +51,9 @@ class Pipeline:
                                       "SURVEY.md §2 #14) and is not implemented")
         # engine extension (tests / data-parallel sharding): Gaussian noise source, shape -> f32 tensor.
         self.randn: Optional[Callable] = None
+        # engine extension (diffbir_amd.parallel): shard the tiles of tiled sampling over (rank, world)
+        self.tile_shard: Optional[Tuple[int, int]] = None
+        self.tile_all_reduce: Optional[Callable] = None
 
     def _randn(self, shape) -> torch.Tensor:
         if self.randn is not None:
@@ -117,6 +120,7 @@ class Pipeline:
         else:
             raise NotImplementedError(sampler_type)
         sampler.randn = self.randn
+        sampler.tile_shard, sampler.tile_all_reduce = self.tile_shard, self.tile_all_reduce
         try:
             z = sampler.sample(model=self.cldm, device=self.device, steps=steps, x_size=(bs, 4, h2, w2), cond=cond,
                                uncond=uncond, cfg_scale=cfg_scale, tiled=cldm_tiled, tile_size=cldm_tile_size // 8,

@@ -13,7 +13,6 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..utils.tiling import TiledModel
 from .sampler import Sampler
 
 
@@ -73,7 +72,7 @@ class DPMSolverSampler(Sampler):
                uncond: Optional[Dict[str, torch.Tensor]], cfg_scale: float, tiled: bool = False, tile_size: int = -1,
                tile_stride: int = -1, x_T: Optional[torch.Tensor] = None, progress: bool = True) -> torch.Tensor:
         ns = NoiseScheduleVP(self.betas)
-        fwd = TiledModel(model.forward, tile_size, tile_stride) if tiled else model.forward
+        fwd = self._tiled(model.forward, tile_size, tile_stride) if tiled else model.forward
         bs = x_size[0]
         if x_T is None:
             x_T = self._randn(x_size, device)

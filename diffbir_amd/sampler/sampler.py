@@ -17,6 +17,13 @@ class Sampler:
         # engine extension: source of Gaussian noise (shape -> f32 tensor on the sampling device). Default is the
         # device generator, exactly what the reference consumes (torch.randn / randn_like on `device`).
         self.randn: Optional[Callable] = None
+        # engine extension (diffbir_amd.parallel): (rank, world) tile shard + all-reduce callable for tiled sampling
+        self.tile_shard = None
+        self.tile_all_reduce: Optional[Callable] = None
+
+    def _tiled(self, forward: Callable, tile_size: int, tile_stride: int):
+        from ..utils.tiling import TiledModel
+        return TiledModel(forward, tile_size, tile_stride, shard=self.tile_shard, all_reduce=self.tile_all_reduce)
 
     def _randn(self, shape, device) -> torch.Tensor:
         if self.randn is not None:

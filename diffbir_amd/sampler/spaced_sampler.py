@@ -11,7 +11,6 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..utils.tiling import TiledModel
 from .sampler import Sampler
 
 
@@ -71,7 +70,7 @@ class SpacedSampler(Sampler):
         bs = x_size[0]
         fwd = model.forward
         if tiled:
-            fwd = TiledModel(model.forward, tile_size, tile_stride)
+            fwd = self._tiled(model.forward, tile_size, tile_stride)
         if x_T is None:
             x_T = self._randn(x_size, device)
         x = x_T.to(device=device, dtype=torch.float32).contiguous()

@@ -175,6 +175,13 @@ int dbir_tile_gather(const float* x, float* tiles, const int* coords, int T, int
                      void* stream);
 int dbir_tile_accumulate(const float* tiles, const float* weights, const int* coords, float* out, int T, int B,
                          int C, int H, int W, int ts, void* stream);
+/* Sharded form (one process per GPU): num = the un-normalised weighted sum over the SUBSET of tiles given
+ * (tile-major [T*B,C,ts,ts] like above; tiles == NULL accumulates the weights alone = the normaliser [H,W] when called
+ * with B = C = 1).  The per-rank partial sums are all-reduced by the host (RCCL), then
+ * dbir_tile_normalize: out[bc, p] = num[bc, p] / den[p]. */
+int dbir_tile_accumulate_partial(const float* tiles, const float* weights, const int* coords, float* num, int T,
+                                 int B, int C, int H, int W, int ts, void* stream);
+int dbir_tile_normalize(const float* num, const float* den, float* out, long long BC, long long HW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pre/post image ops (pipeline.py:265-271, 306-320; utils/common.py:29-77). */

@@ -261,6 +261,18 @@ def tile_accumulate(tiles, weights, coords, B, H, W):
     return out / cnt
 
 
+def tile_accumulate_partial(tiles, weights, coords, B, C, H, W):
+    ts = weights.shape[-1]
+    out = torch.zeros((B, C, H, W), dtype=torch.float32, device=weights.device)
+    for t, (h, w) in enumerate(coords.tolist()):
+        out[..., h:h + ts, w:w + ts] += weights if tiles is None else tiles[t * B:(t + 1) * B] * weights
+    return out
+
+
+def tile_normalize(num, den):
+    return num / den.reshape(num.shape[-2:])
+
+
 def u8_to_f32_nchw(src):
     return src.float().div(255).clamp(0, 1).permute(0, 3, 1, 2).contiguous()
 
@@ -284,7 +296,8 @@ def f32_nchw_to_u8_nhwc(src):
 
 _NAMES = ["linear", "linear_t", "conv3x3", "bmm_nt", "attention", "window_attention", "groupnorm", "layernorm",
           "softmax_rows_", "add_scaled", "nchw_to_nhwc", "nhwc_to_nchw", "pixel_unshuffle", "timestep_embedding",
-          "lincomb4", "spaced_step", "tile_gather", "tile_accumulate", "u8_to_f32_nchw", "wavelet_blur", "colorfix",
+          "lincomb4", "spaced_step", "tile_gather", "tile_accumulate", "tile_accumulate_partial", "tile_normalize",
+          "u8_to_f32_nchw", "wavelet_blur", "colorfix",
           "f32_nchw_to_u8_nhwc"]
 
 

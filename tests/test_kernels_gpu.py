@@ -424,6 +424,20 @@ def test_sampler_and_tiles_f32():
     wt = torch.tensor(gaussian_weights(ts, ts), dtype=torch.float32, device=DEV)
     ev = rnd(*tiles.shape, dtype=torch.float32, seed=5)
     check("tile_accumulate", ops.tile_accumulate(ev, wt, coords, 2, H, W), emu.tile_accumulate(ev, wt, coords, 2, H, W), torch.float32, 0.01)
+    # sharded form (diffbir_amd.parallel): two round-robin shards, summed, normalised == the one-pass result
+    num = torch.zeros(2, 4, H, W, device=DEV)
+    Tn = coords.shape[0]
+    for r in range(2):
+        ids = torch.arange(r, Tn, 2, device=DEV)
+        sub = ev.reshape(Tn, 2, 4, ts, ts)[ids].reshape(-1, 4, ts, ts).contiguous()
+        part = ops.tile_accumulate_partial(sub, wt, coords[ids].contiguous(), 2, 4, H, W)
+        check(f"tile_accumulate_partial shard {r}", part, emu.tile_accumulate_partial(sub, wt, coords[ids], 2, 4, H, W),
+              torch.float32, 0.01)
+        num += part
+    den = ops.tile_accumulate_partial(None, wt, coords, 1, 1, H, W)
+    check("tile normaliser", den, emu.tile_accumulate_partial(None, wt, coords, 1, 1, H, W), torch.float32, 0.01)
+    check("tile_normalize(sharded)", ops.tile_normalize(num, den), emu.tile_accumulate(ev, wt, coords, 2, H, W),
+          torch.float32, 0.01)
 
 
 def test_image_io_f32():

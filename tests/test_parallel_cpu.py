@@ -1,0 +1,106 @@
+"""Multi-process (world_size 2, gloo, CPU) coverage of diffbir_amd.parallel: batch sharding with full-batch noise
+parity, tile sharding with the per-evaluation all-reduce, weight broadcast and output gather.  The kernels are
+replaced by the PyTorch test double (tests/emu_ops.py) exactly as in test_engine_wiring_cpu.py; results are compared
+with the reference-generated golden vectors and with the single-process engine."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from diffbir_amd import parallel
+
+
+def test_shard_range_covers_and_balances():
+    for n in (0, 1, 2, 7, 8, 32, 49, 225):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sharded_noise_equals_full_batch_rows():
+    from oracle.cases import NoiseStream
+    full = NoiseStream(5)
+    a, b = full((4, 4, 8, 8)), full((4, 4, 8, 8))
+    for r in range(2):
+        lo, hi = parallel.shard_range(4, r, 2)
+        sn = parallel.ShardedNoise(NoiseStream(5), 4, lo, hi)
+        assert torch.equal(sn((hi - lo, 4, 8, 8)), a[lo:hi])
+        assert torch.equal(sn((hi - lo, 4, 8, 8)), b[lo:hi])
+
+
+class _Patch:
+    """Minimal stand-in for pytest's monkeypatch inside spawned workers."""
+
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, outdir: str):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import cases
+    from tests import emu_ops
+    from tests.helpers import build_engine
+    emu_ops.install(_Patch())
+    ctx = parallel.init_distributed("gloo", torch.device("cpu"))
+    assert ctx.world == world and ctx.rank == rank
+    with torch.no_grad():
+        pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", torch.device("cpu"), torch.float32, raw_dtype=True)
+
+        # ---- weight broadcast: rank 1 starts from garbage, receives rank 0's SwinIR weights
+        sd0 = swin.state_dict()
+        src = sd0 if rank == 0 else {k: torch.full_like(v, 7.0) for k, v in sd0.items()}
+        got = parallel.broadcast_state_dict(src, swin._spec, ctx, bucket_bytes=1 << 16)
+        assert set(got) == set(sd0) and all(torch.equal(got[k], sd0[k].float()) for k in sd0)
+
+        def args(steps, sampler, tiled=False):
+            return (steps, 1.0, False, 512, 256, False, 256, False, 256, tiled, 512, 256, "", cases.NEG_PROMPT, 4.0,
+                    "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
+
+        # ---- batch sharding: golden case spaced4_b2_v21 (2 images, seed 99) -> one image per rank
+        lq = cases.make_lq(5, 2, 512, 512)
+        out = parallel.run_data_parallel(pipe, lq, ctx, args(4, "spaced"), noise=cases.NoiseStream(99))
+        if rank == 0:
+            np.save(os.path.join(outdir, "dp.npy"), out)
+        else:
+            assert out is None
+
+        # ---- tile sharding: golden case spaced3_tiled_v21 (600x712 -> 75x89 latent, 64/32 windows)
+        parallel.enable_tile_sharding(pipe, ctx)
+        assert pipe.tile_shard == (rank, world)
+        pipe.randn = cases.NoiseStream(5)
+        lq = cases.make_lq(9, 1, 600, 712)
+        out = pipe.run(lq, *args(3, "spaced", tiled=True))
+        np.save(os.path.join(outdir, f"tiled_{rank}.npy"), out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_world2_gloo_matches_reference_golden(golden_dir):
+    from oracle import cases
+    world, port = 2, _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_worker, args=(world, port, outdir), nprocs=world, join=True)
+        ref = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))
+        dp = np.load(os.path.join(outdir, "dp.npy"))
+        assert dp.shape == ref["spaced4_b2_v21"].shape and dp.dtype == np.uint8
+        assert cases.psnr_u8(dp, ref["spaced4_b2_v21"]) > 60.0
+        t0, t1 = (np.load(os.path.join(outdir, f"tiled_{r}.npy")) for r in range(2))
+        assert np.array_equal(t0, t1), "ranks must agree after the all-reduce (redundant sampler update)"
+        # the parallel reduction changes the f32 summation order of the tile blend: tolerance, not bit-exactness
+        assert cases.psnr_u8(t0, ref["spaced3_tiled_v21"]) > 55.0
