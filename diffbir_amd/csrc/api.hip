@@ -13,4 +13,4 @@ void dbir_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dbir_last_error(void) { return g_err; }
-extern "C" int dbir_abi_version(void) { return 1; }
+extern "C" int dbir_abi_version(void) { return 2; }
