@@ -14,3 +14,16 @@ void dbir_set_error(const char* fmt, ...) {
 
 extern "C" const char* dbir_last_error(void) { return g_err; }
 extern "C" int dbir_abi_version(void) { return 2; }
+
+void dbir_attention_set_variant(int v);  // attention.hip
+
+extern "C" int dbir_set_option(int key, int value) {
+  switch (key) {
+    case DBIR_OPT_ATTN_VARIANT:
+      DBIR_CHECK_ARG(value == 1 || value == 2, "dbir_set_option: attention variant must be 1 or 2");
+      dbir_attention_set_variant(value);
+      return DBIR_OK;
+  }
+  dbir_set_error("dbir_set_option: unknown key %d", key);
+  return DBIR_ERR_ARG;
+}

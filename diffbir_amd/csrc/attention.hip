@@ -171,7 +171,198 @@ __global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ Q, lo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 2 (default): same decomposition and register dataflow as attn_kernel above, restructured for issue slots.
+// At head_dim 64 a 64-key tile is only 16 MFMAs (512 matrix cycles) per wave against >300 VALU ops of softmax in
+// variant 1, so the kernel is VALU-bound; and its K/V staging is synchronous (global -> LDS between two barriers).
+//   * K / V^T tiles are double-buffered in LDS; the next tile's global loads are issued into registers BEFORE the
+//     current tile's MFMAs and written to the other buffer after them (guide T14): one barrier per tile, L2/HBM
+//     latency hidden under the compute.
+//   * softmax VALU diet: the softmax scale is folded into the exponent (p = exp2(s*c - m), one v_fma + one v_exp
+//     per score instead of mul, sub, exp), the row max is taken on raw scores (c > 0), the key mask only runs on a
+//     ragged last tile, and the O / l rescale is skipped while the running max grows by less than 2^8 for every
+//     row of the wave (guide T13; P is then bounded by 256, exact in f32 and well inside f16 / bf16 range; the
+//     decision precedes the tile's exponentials and its P.V, the textbook order).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q, long long q_bs, long long ldq,
+                                                       const u16* __restrict__ K, long long k_bs, long long ldk,
+                                                       const u16* __restrict__ Vt, long long vt_bs, long long ldvt,
+                                                       u16* __restrict__ O, long long o_bs, long long ldo, int H,
+                                                       int Lq, int Lk, float c /* scale * log2(e) */) {
+  constexpr int KS_HALFS = KT * K_LD, VS_HALFS = 64 * V_LD;
+  __shared__ __attribute__((aligned(16))) u16 lds[2 * (KS_HALFS + VS_HALFS)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int q_row = blockIdx.x * 128 + wave * 32 + lq;
+  const bool q_ok = q_row < Lq;
+
+  typename T::vec8 qf[4];
+  {
+    const u16* qp = Q + (long long)b * q_bs + (long long)(q_ok ? q_row : 0) * ldq + h * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 v = q_ok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
+      qf[ks] = __builtin_bit_cast(typename T::vec8, v);
+    }
+  }
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;  // m_run in the scaled log2 domain
+
+  const u16* Kg = K + (long long)b * k_bs + h * 64;
+  const u16* Vg = Vt + (long long)b * vt_bs + (long long)(h * 64) * ldvt;
+  const int kc = tid & 7, r0 = tid >> 3;
+  const int ntiles = (Lk + KT - 1) / KT;
+
+  uint4 kreg[2], vreg[2];
+  auto fetch = [&](int kt) {  // global -> registers (zero-filled outside [0, Lk))
+    const int key0 = kt * KT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = r0 + 32 * i;
+      const int key = key0 + row;
+      kreg[i] = make_uint4(0, 0, 0, 0);
+      if (key < Lk) kreg[i] = *reinterpret_cast<const uint4*>(Kg + (long long)key * ldk + kc * 8);
+      const int kcol = key0 + kc * 8;
+      uint4 vv = make_uint4(0, 0, 0, 0);
+      if (kcol < Lk) vv = *reinterpret_cast<const uint4*>(Vg + (long long)row * ldvt + kcol);
+      vreg[i] = vv;
+    }
+  };
+  auto commit = [&](int buf, int kt) {  // registers -> LDS buffer (touching the loaded values only here keeps the
+                                        // loads asynchronous: no vmcnt wait before this point)
+    u16* Ks = lds + buf * (KS_HALFS + VS_HALFS);
+    u16* Vs = Ks + KS_HALFS;
+    const int kcol = kt * KT + kc * 8;
+    if (kt * KT + KT > Lk) {  // ragged last tile: pad columns of V^T may hold anything -> zero keys >= Lk
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        u16* hv = reinterpret_cast<u16*>(&vreg[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (kcol + e >= Lk) hv[e] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = r0 + 32 * i;
+      *reinterpret_cast<uint4*>(&Ks[row * K_LD + kc * 8]) = kreg[i];
+      uint2* dst = reinterpret_cast<uint2*>(&Vs[row * V_LD + kc * 8]);
+      dst[0] = make_uint2(vreg[i].x, vreg[i].y);
+      dst[1] = make_uint2(vreg[i].z, vreg[i].w);
+    }
+  };
+
+  fetch(0);
+  commit(0, 0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int key0 = kt * KT;
+    const u16* Ks = lds + (kt & 1) * (KS_HALFS + VS_HALFS);
+    const u16* Vs = Ks + KS_HALFS;
+    const bool more = kt + 1 < ntiles;
+    if (more) fetch(kt + 1);  // in flight during this tile's MFMAs
+
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        typename T::vec8 kf =
+            *reinterpret_cast<const typename T::vec8*>(&Ks[(kb * 32 + lq) * K_LD + ks * 16 + hi * 8]);
+        s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
+      }
+    }
+    if (key0 + KT > Lk) {  // ragged last tile: mask keys >= Lk (wave-uniform branch)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= Lk) s_acc[kb][r] = -1e30f;
+        }
+    }
+    float mx = s_acc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * c;
+    if (!__all(mxs - m_run <= 8.0f)) {  // some row's max grew by more than 2^8: rescale everything once
+      const float m_new = fmaxf(m_run, mxs);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+    }
+    float psum = 0.f;
+    const float neg_m = -m_run;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], c, neg_m));
+        s_acc[kb][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run += psum;
+
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float pf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = s_acc[s >> 1][8 * (s & 1) + j];
+      const uint4 pp = pack8<T>(pf);
+      const typename T::vec8 pfrag = __builtin_bit_cast(typename T::vec8, pp);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u16* vrow = &Vs[(t * 32 + lq) * V_LD + 16 * s + 4 * hi];
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+        const uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
+      }
+    }
+    if (more) commit((kt + 1) & 1, kt + 1);  // the other buffer was last read in iteration kt-1 (barrier since)
+    __syncthreads();
+  }
+
+  if (q_ok) {
+    const float inv = 1.0f / l_run;
+    u16* op = O + (long long)b * o_bs + (long long)q_row * ldo + h * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16 hv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = T::from_f32(o_acc[t][4 * g + e] * inv);
+        uint2 pk;
+        pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+        pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+        *reinterpret_cast<uint2*>(op + t * 32 + 8 * g + 4 * hi) = pk;
+      }
+  }
+}
+
+int g_attn_variant = 2;
+
 }  // namespace
+
+// tuning / A-B switch (dbir_set_option): 1 = synchronous-staging kernel, 2 = double-buffered + VALU-diet kernel
+void dbir_attention_set_variant(int v) { g_attn_variant = v; }
 
 extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, long long ldq, const void* K,
                               long long k_bstride, long long ldk, const void* Vt, long long vt_bstride,
@@ -187,6 +378,20 @@ extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, lon
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(cdiv(Lq, 128), B * H);
   const float sl2 = scale * 1.4426950408889634f;
+  if (dtype != DBIR_F16 && dtype != DBIR_BF16) {
+    dbir_set_error("dbir_attention: bad dtype %d", dtype);
+    return DBIR_ERR_ARG;
+  }
+  if (g_attn_variant == 2) {
+    if (dtype == DBIR_F16)
+      hipLaunchKernelGGL((attn2_kernel<F16>), grid, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
+                         k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
+    else
+      hipLaunchKernelGGL((attn2_kernel<BF16>), grid, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
+                         k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
+    DBIR_CHECK_LAUNCH("dbir_attention");
+    return DBIR_OK;
+  }
   if (dtype == DBIR_F16)
     hipLaunchKernelGGL((attn_kernel<F16>), grid, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
                        k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);

@@ -5,11 +5,11 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p build
-for f in api gemm gemm_glds attention norm elementwise swin; do
+for f in api gemm gemm_glds gemm_ph attention norm elementwise swin; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/dbir.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
   fi
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC build/api.o build/gemm.o build/gemm_glds.o build/attention.o build/norm.o build/elementwise.o build/swin.o -o ../libdbir_hip.so
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/api.o build/gemm.o build/gemm_glds.o build/gemm_ph.o build/attention.o build/norm.o build/elementwise.o build/swin.o -o ../libdbir_hip.so
 echo "built $(pwd)/../libdbir_hip.so"

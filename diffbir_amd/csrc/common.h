@@ -14,6 +14,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef unsigned short u16;
 
 // ---- 16-bit element traits: storage is always raw u16; math in f32 ---------------------------
@@ -21,6 +24,11 @@ struct F16 {
   typedef f16x8 vec8;
   static __device__ __forceinline__ float to_f32(u16 v) { return (float)__builtin_bit_cast(f16, v); }
   static __device__ __forceinline__ u16 from_f32(float v) { return __builtin_bit_cast(u16, (f16)v); }
+  // two f32 -> packed 16-bit pair (a in the low half), round-to-nearest-even: one v_cvt_pk_f16_f32 on gfx950
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  }
   static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
@@ -29,6 +37,10 @@ struct BF16 {
   typedef bf16x8 vec8;
   static __device__ __forceinline__ float to_f32(u16 v) { return __builtin_bit_cast(float, ((uint32_t)v) << 16); }
   static __device__ __forceinline__ u16 from_f32(float v) { return __builtin_bit_cast(u16, (__bf16)v); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {  // one v_cvt_pk_bf16_f32
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  }
   static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
@@ -42,11 +54,7 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
 }
 template <typename T>
 __device__ __forceinline__ uint4 pack8(const float* f) {
-  uint4 v;
-  u16* h = reinterpret_cast<u16*>(&v);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) h[i] = T::from_f32(f[i]);
-  return v;
+  return make_uint4(T::pack2(f[0], f[1]), T::pack2(f[2], f[3]), T::pack2(f[4], f[5]), T::pack2(f[6], f[7]));
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

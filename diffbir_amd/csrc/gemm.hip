@@ -271,6 +271,8 @@ int dispatch(const GemmParams& p, int tile, hipStream_t s) {
 // direct-to-LDS variant (gemm_glds.hip)
 bool dbir_gemm_glds_eligible(const dbir_gemm_desc& d);
 int dbir_gemm_glds(const dbir_gemm_desc& d, int Hv, int Wv, int tile, hipStream_t s);
+// phased two-group 256x256 kernel (gemm_ph.hip), tile 13
+int dbir_gemm_ph(const dbir_gemm_desc& d, int Hv, int Wv, hipStream_t s);
 
 extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   DBIR_CHECK_ARG(dd && dd->A && dd->W && dd->C, "dbir_gemm: null pointer");
@@ -300,11 +302,12 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 12, "dbir_gemm: bad tile %d", tile);
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 13, "dbir_gemm: bad tile %d", tile);
   if (tile == 0 || tile >= 5) {
     const bool ok = dbir_gemm_glds_eligible(d);
     DBIR_CHECK_ARG(ok || tile == 0, "dbir_gemm: tile %d (direct-to-LDS kernel) needs K/Cin %% 64 == 0, 16-byte aligned "
                    "operands and a 16-bit row-major output", tile);
+    if (ok && tile == 13) return dbir_gemm_ph(d, p.Hv, p.Wv, reinterpret_cast<hipStream_t>(stream));
     if (ok) return dbir_gemm_glds(d, p.Hv, p.Wv, tile, reinterpret_cast<hipStream_t>(stream));
   }
   if (tile == 0) {

@@ -62,6 +62,7 @@ SIGNATURES = {
     "dbir_colorfix": [_P, _P, _P, _P, _LL, _P],
     "dbir_f32_nchw_to_u8_nhwc": [_P, _P, _I, _I, _I, _P],
     "dbir_abi_version": [],
+    "dbir_set_option": [_I, _I],
 }
 
 _lib = None

@@ -36,6 +36,10 @@ extern "C" {
 
 const char* dbir_last_error(void);
 int dbir_abi_version(void);
+/* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 1 = synchronous-staging
+ * attention kernel, 2 (default) = double-buffered kernel with the folded-scale softmax. */
+#define DBIR_OPT_ATTN_VARIANT 1
+int dbir_set_option(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * dbir_gemm — fused implicit-GEMM on MFMA: C = epilogue(A (*) W^T)
@@ -84,7 +88,7 @@ typedef struct dbir_gemm_desc {
   int batch;
   int tile; /* 0 = auto; generic kernel 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64; direct-to-LDS kernel 5: 128x128,
                6: 256x64, 7: 64x256, 8/9: 256x128 (4 / 8 waves, 3-stage ring), 10: 256x256, 11: 128x128 4-stage,
-               12: 256x128 2-stage (testing / tuning) */
+               12: 256x128 2-stage; 13: phased two-group 256x256 (gemm_ph.hip) (testing / tuning) */
 } dbir_gemm_desc;
 int dbir_gemm(const dbir_gemm_desc* d, void* stream);
 

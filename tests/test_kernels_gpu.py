@@ -187,7 +187,7 @@ def test_conv3x3_fused_epilogue(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
-GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12]
+GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -299,14 +299,61 @@ def test_glds_deterministic():
         assert torch.equal(a, ops.conv3x3(x, pw))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_phased_gemm_race_screen(dtype):
+    """Tile 13 (two staggered wave groups, counted vmcnt across barriers) at full-chip sizes, repeated, against the
+    2-stage 128x128 kernel (tile 5).  Both kernels feed every output element the same MFMA sequence (K tiles in order,
+    16 k per instruction), so the results must be BIT-identical: any LDS read-before-land / restage-before-read race
+    shows up as a differing tile even when it is rare."""
+    cases = []
+    x = rnd(16, 64, 64, 320, dtype=dtype)
+    pw = ops.pack_conv3x3(rnd(320, 320, 3, 3, dtype=torch.float32, s=0.02, seed=1).cpu(),
+                          rnd(320, dtype=torch.float32, seed=2).cpu(), dtype, DEV)
+    emb = rnd(16, 320, dtype=dtype, seed=3)
+    cases.append(("conv 16x64x64 320->320 +emb", lambda t: ops.conv3x3(x, pw, rowvec=emb, tile=t)))
+    x2 = rnd(16, 16, 16, 1280, dtype=dtype, seed=4)
+    pw2 = ops.pack_conv3x3(rnd(1280, 1280, 3, 3, dtype=torch.float32, s=0.01, seed=5).cpu(), None, dtype, DEV)
+    cases.append(("conv 16x16x16 1280->1280", lambda t: ops.conv3x3(x2, pw2, tile=t)))
+    x3 = rnd(16384, 2560, dtype=dtype, seed=6)
+    pw3 = ops.pack_linear(rnd(640, 2560, dtype=torch.float32, s=0.02, seed=7).cpu(), None, dtype, DEV)
+    res = rnd(16384, 640, dtype=dtype, seed=8)
+    cases.append(("linear 16384x640x2560 +res", lambda t: ops.linear(x3, pw3, residual=res, tile=t)))
+    x4 = rnd(65536, 320, dtype=dtype, seed=9)
+    pw4 = ops.pack_geglu(rnd(2560, 320, dtype=torch.float32, s=0.05, seed=10).cpu(),
+                         rnd(2560, dtype=torch.float32, seed=11).cpu(), dtype, DEV)
+    cases.append(("geglu 65536x1280x320", lambda t: ops.linear(x4, pw4, tile=t)))
+    x5 = rnd(8, 33, 47, 64, dtype=dtype, seed=12)   # ragged M, odd image, single channel tile per tap
+    pw5 = ops.pack_conv3x3(rnd(200, 64, 3, 3, dtype=torch.float32, s=0.05, seed=13).cpu(), None, dtype, DEV)
+    cases.append(("conv 8x33x47 64->200 s2", lambda t: ops.conv3x3(x5, pw5, stride=2, tile=t)))
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    for name, fn in cases:
+        ref = fn(5).clone().float()
+        for it in range(6):
+            got = fn(13).float()
+            # identical MFMA sequences -> normally bit-identical; allow 1 ulp for epilogue FMA-contraction differences
+            # between the two translation units.  A staging race corrupts whole K tiles: orders of magnitude larger.
+            bad = (got - ref).abs() > ulp * ref.abs() + 1e-6
+            assert not bad.any(), f"{name}: tile 13 differs from tile 5 (iteration {it}): " \
+                f"{(got - ref).abs().max().item():.3e} max abs, {bad.float().mean().item():.2e} of the elements"
+
+
 # ------------------------------------------------------------------------------------------------ attention
 ATT_CASES = [(2, 5, 1024, 1024), (1, 10, 256, 256), (2, 20, 64, 64), (2, 5, 1024, 77), (1, 2, 100, 77),
              (1, 1, 4096, 4096), (3, 4, 37, 200), (2, 20, 64, 77)]
 
 
+@pytest.fixture(params=[2, 1], ids=["attn_v2", "attn_v1"])
+def attn_variant(request):
+    """Both attention kernels (include/dbir.h DBIR_OPT_ATTN_VARIANT); the default (2) is restored afterwards."""
+    from diffbir_amd import native
+    native.check(native.lib().dbir_set_option(1, request.param), "dbir_set_option")
+    yield request.param
+    native.check(native.lib().dbir_set_option(1, 2), "dbir_set_option")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,Lq,Lk", ATT_CASES)
-def test_attention(B, H, Lq, Lk, dtype):
+def test_attention(B, H, Lq, Lk, dtype, attn_variant):
     C = H * 64
     q_wide = rnd(B, Lq, 2 * C, dtype=dtype)
     q = q_wide[..., :C] if Lq == Lk else q_wide[..., C:]
@@ -322,13 +369,15 @@ def test_attention(B, H, Lq, Lk, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_peaked_softmax(dtype):
-    """online-softmax rescale path: one key dominates late in the sequence."""
+def test_attention_peaked_softmax(dtype, attn_variant):
+    """online-softmax rescale path: one key dominates late in the sequence (forces the deferred-rescale branch of
+    variant 2 at a chosen tile, guide rule 26), and a second spike below the 2^8 threshold exercises the defer path."""
     B, H, L = 1, 2, 512
     C = H * 64
     q, k = rnd(B, L, C, dtype=dtype), rnd(B, L, C, dtype=dtype, seed=1)
     k[:, 300] = q[:, 7] * 4.0
     k[:, 17] = q[:, 450] * 3.0
+    k[:, 400] = q[:, 100] * 0.5   # raw score ~ 32 -> scaled log2 growth ~ 5.8 < 8: max is NOT updated for that row
     vt = rnd(B, C, L, dtype=dtype, seed=2)
     oa, ob = torch.zeros(B, L, C, dtype=dtype, device=DEV), torch.zeros(B, L, C, dtype=dtype, device=DEV)
     ops.attention(q, k, vt, oa, H, L, 0.125)
