@@ -307,9 +307,12 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
     const bool ok = dbir_gemm_glds_eligible(d);
     DBIR_CHECK_ARG(ok || tile == 0, "dbir_gemm: tile %d (direct-to-LDS kernel) needs K/Cin %% 64 == 0, 16-byte aligned "
                    "operands and a 16-bit row-major output", tile);
+    DBIR_CHECK_ARG(d.splitk <= 1 || (ok && tile != 13), "dbir_gemm: split-K is implemented by the direct-to-LDS "
+                   "kernel only (tiles 5-12, eligible operands)");
     if (ok && tile == 13) return dbir_gemm_ph(d, p.Hv, p.Wv, reinterpret_cast<hipStream_t>(stream));
     if (ok) return dbir_gemm_glds(d, p.Hv, p.Wv, tile, reinterpret_cast<hipStream_t>(stream));
   }
+  DBIR_CHECK_ARG(d.splitk <= 1, "dbir_gemm: split-K needs the direct-to-LDS kernel (tile 5-12)");
   if (tile == 0) {
     // largest tile that still yields >= ~1.5 waves of blocks over the 256 CUs; GEGLU needs NJ == 2.
     const long long z = d.batch;

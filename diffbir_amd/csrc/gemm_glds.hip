@@ -41,6 +41,8 @@ struct G2Params {
   int ntaps;    // 9 (conv) / 1 (linear)
   int mtiles, ntiles;
   int vec_bias, vec_rv;  // bias / row vector may be read with 16 B / 8 B vector loads
+  int splitk, kt_per;    // split-K: number of K slices (1 = off) and K tiles per slice
+  float* ws;             // split-K: f32 partial sums [z][slice][M][N]
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -87,11 +89,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   const int bz = blockIdx.y;
 
   // ---- XCD-aware tile mapping (bijective) ----
-  int tm, tn;
+  int tm, tn, ksp;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int tiles = p.mtiles * p.ntiles;
+    ksp = lid / tiles;  // K slice (0 when split-K is off)
+    lid -= ksp * tiles;
     tn = lid % p.ntiles;
     tm = lid / p.ntiles;
   }
@@ -140,8 +145,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     w_rp[i] = w_rv[i] ? Wg + (long long)n * d.Kpad + cch : zp;
   }
 
-  // staging cursor (uniform): tile index, tap, channel-tile within the tap, ring slot
-  int s_kt = 0, s_tap = 0, s_cc = 0, s_slot = 0;
+  // staging cursor (uniform): tile index, tap, channel-tile within the tap, ring slot.  With split-K this block owns
+  // K tiles [kt0, kt0 + nk).
+  const int kt0 = ksp * p.kt_per;
+  int s_kt = kt0, s_tap = kt0 / p.nkc, s_slot = 0;
+  int s_cc = kt0 - s_tap * p.nkc;
 
 #define SET_TAP()                                                                                   \
   do {                                                                                              \
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.nkc * p.ntaps;
+  const int nk = (p.nkc * p.ntaps - kt0 < p.kt_per) ? p.nkc * p.ntaps - kt0 : p.kt_per;
   SET_TAP();
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
@@ -235,9 +243,29 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
 #undef STAGE
 #undef SET_TAP
 
+  const int N = d.N;
+  if (p.splitk > 1) {
+    // split-K: raw f32 partial sums to the workspace; bias / epilogue / 16-bit store happen in splitk_reduce_kernel
+    float* __restrict__ wsp = p.ws + ((long long)bz * p.splitk + ksp) * (long long)M * N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = tm * BM + wm * 32 * MI + i * 32 + lq;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = tn * BN + wn * 32 * NJ + j * 32 + 8 * g + 4 * hi;
+          if (n0 + 4 <= N) {  // N % 8 == 0 is required for split-K, so 16-byte aligned
+            *reinterpret_cast<float4*>(wsp + (long long)m * N + n0) =
+                make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          }
+        }
+    }
+    return;
+  }
   // ---------------- epilogue: f32 math in registers -> 16-bit tile in LDS -> row-contiguous 16 B stores ----------
   const bool geglu = d.act == DBIR_ACT_GEGLU;
-  const int N = d.N;
   const int bn_out = geglu ? BN / 2 : BN;
   const int cs_ld = bn_out + 8;  // halfs; (bn_out + 8) * 2 B is a multiple of 16
   u16* Cs = reinterpret_cast<u16*>(smem);
@@ -359,6 +387,58 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   }
 }
 
+// Split-K second pass: sum the K slices in a fixed order (deterministic), then the same epilogue as the fused path
+// (bias, row vector, activation, scale, residual) and the 16-bit store.  One thread = 8 consecutive columns.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
+  const dbir_gemm_desc& d = p.d;
+  const int M = d.M, N = d.N, n8 = N >> 3;
+  const long long total = (long long)M * n8;
+  const int bz = blockIdx.y;
+  const float* __restrict__ wsp = p.ws + (long long)bz * p.splitk * (long long)M * N;
+  const u16* __restrict__ RV = reinterpret_cast<const u16*>(d.rowvec);
+  const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) + (long long)bz * d.strideR_z : nullptr;
+  u16* __restrict__ Cg = reinterpret_cast<u16*>(d.C) + (long long)bz * d.strideC_z;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int m = (int)(q / n8), n0 = (int)(q - (long long)m * n8) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int sidx = 0; sidx < p.splitk; ++sidx) {
+      const float4* src = reinterpret_cast<const float4*>(wsp + ((long long)sidx * M + m) * N + n0);
+      const float4 a = src[0], b = src[1];
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+      v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (d.bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += d.bias[n0 + e];
+    }
+    if (RV) {
+      const u16* rvp = RV + (long long)(m / d.rows_per_batch) * d.rowvec_ld + n0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += T::to_f32(rvp[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e];
+      if (d.act == DBIR_ACT_SILU) x = silu_f(x);
+      else if (d.act == DBIR_ACT_GELU) x = gelu_fast(x);
+      else if (d.act == DBIR_ACT_LRELU) x = x > 0.f ? x : x * d.act_param;
+      // same rounding points as the fused epilogue: round to 16 bit, then add the residual in f32, round again
+      v[e] = T::to_f32(T::from_f32(x * d.out_scale));
+    }
+    if (Rg) {
+      const uint4 rr = *reinterpret_cast<const uint4*>(Rg + (long long)m * d.ldr + n0);
+      float b8[8];
+      unpack8<T>(rr, b8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += b8[e];
+    }
+    *reinterpret_cast<uint4*>(Cg + (long long)m * d.ldc + n0) = pack8<T>(v);
+  }
+}
+
 template <typename T, int WM, int WN, int MI, int NJ, int STAGES>
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
@@ -376,9 +456,16 @@ int launch2(G2Params& p, hipStream_t s) {
   }
   p.mtiles = cdiv(p.d.M, BM);
   p.ntiles = cdiv(p.d.N, BN);
-  dim3 grid((unsigned)(p.mtiles * p.ntiles), p.d.batch > 0 ? p.d.batch : 1);
+  const unsigned nz = p.d.batch > 0 ? p.d.batch : 1;
+  dim3 grid((unsigned)(p.mtiles * p.ntiles * p.splitk), nz);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
   DBIR_CHECK_LAUNCH("dbir_gemm(glds)");
+  if (p.splitk > 1) {
+    const long long work = (long long)p.d.M * (p.d.N >> 3);
+    const unsigned rb = (unsigned)(work / 256 + 1 < 4096 ? work / 256 + 1 : 4096);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb, nz), dim3(256), 0, s, p);
+    DBIR_CHECK_LAUNCH("dbir_gemm(split-K reduce)");
+  }
   return DBIR_OK;
 }
 
@@ -431,6 +518,27 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
   }
   p.vec_bias = dd.bias && (reinterpret_cast<uintptr_t>(dd.bias) & 15) == 0;
   p.vec_rv = dd.rowvec && (reinterpret_cast<uintptr_t>(dd.rowvec) & 7) == 0 && dd.rowvec_ld % 4 == 0;
+  {
+    // split-K (explicit request only): slices of whole K tiles; every slice must be non-empty
+    const int nk_total = p.nkc * p.ntaps;
+    int sk = dd.splitk > 1 ? dd.splitk : 1;
+    if (sk > nk_total) sk = nk_total;
+    p.kt_per = cdiv(nk_total, sk);
+    p.splitk = cdiv(nk_total, p.kt_per);
+    p.ws = reinterpret_cast<float*>(dd.ws);
+    if (p.splitk > 1) {
+      const long long need = (long long)p.splitk * (dd.batch > 0 ? dd.batch : 1) * dd.M * dd.N * 4;
+      if (!dd.ws || dd.ws_bytes < need || (reinterpret_cast<uintptr_t>(dd.ws) & 15)) {
+        dbir_set_error("dbir_gemm: split-K %d needs a 16-byte aligned workspace of %lld bytes (got %lld)", p.splitk,
+                       need, dd.ws_bytes);
+        return DBIR_ERR_ARG;
+      }
+      if (dd.act == DBIR_ACT_GEGLU || dd.N % 8 != 0 || dd.ldc % 8 != 0) {
+        dbir_set_error("dbir_gemm: split-K needs N %% 8 == 0 and no GEGLU");
+        return DBIR_ERR_ARG;
+      }
+    }
+  }
   if (tile == 0) {
     // Tile choice from the MI355X microbenchmarks (tools/bench_kernels.py, profiles/kbench_r1.json):
     //   256x256 (tile 10, 128x64 per wave: fewest LDS reads per MFMA) whenever N wastes <= 20 % of 256-wide column

@@ -31,6 +31,7 @@ class GemmDesc(Structure):
         ("out_f32", c_int), ("store_mode", c_int), ("trans_L", c_int),
         ("trans_ld", c_longlong), ("trans_bstride", c_longlong),
         ("batch", c_int), ("tile", c_int),
+        ("splitk", c_int), ("ws", c_void_p), ("ws_bytes", c_longlong),
     ]
 
 

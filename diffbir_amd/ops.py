@@ -17,7 +17,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import native
+from . import native, tuning
 from .native import (ACT_GEGLU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_SILU, MODE_CONV3X3, MODE_LINEAR,  # noqa: F401
                      GemmDesc)
 
@@ -171,14 +171,46 @@ class _Timed:
         return False
 
 
+_TUNER = None  # tools/autotune.py installs an object with .run(d, out) while measuring tile variants
+_WS = {}       # device -> f32 split-K workspace (grown on demand, reused by every launch on that device's stream)
+
+
+def splitk_workspace(device, nbytes: int) -> T:
+    ws = _WS.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20) // 4, dtype=torch.float32, device=device)
+        _WS[device] = ws
+    return ws
+
+
+def apply_tile_code(d: GemmDesc, code: int, device) -> None:
+    """code = tile id + 100 * split-K factor (diffbir_amd/tuning.py)."""
+    d.tile, sk = code % 100, code // 100
+    if sk > 1:
+        ws = splitk_workspace(device, sk * max(d.batch, 1) * d.M * d.N * 4)
+        d.splitk, d.ws, d.ws_bytes = sk, ws.data_ptr(), ws.numel() * 4
+    else:
+        d.splitk, d.ws, d.ws_bytes = 0, None, 0
+
+
 def _gemm_launch(d: GemmDesc, keep):
+    out = keep[2]
+    from_table = False
+    if d.tile == 0 and d.store_mode == 0 and not d.out_f32:
+        code = _TUNER.run(d, out) if _TUNER is not None else tuning.lookup(d)
+        from_table = code != 0
+        apply_tile_code(d, code, out.device)
     tag = ""
     if _PROFILE is not None:
         tag = (f"{'conv' if d.mode == MODE_CONV3X3 else 'lin'} M{d.M} N{d.N} K{d.K} z{max(d.batch, 1)} act{d.act}"
                f"{' s2' if d.stride == 2 else ''}{' up' if d.upsample else ''}{' T' if d.store_mode else ''}"
-               f"{' f32' if d.out_f32 else ''}{' res' if d.R else ''}")
+               f"{' f32' if d.out_f32 else ''}{' res' if d.R else ''} t{d.tile}{'k%d' % d.splitk if d.splitk > 1 else ''}")
     with _Timed("gemm", 2.0 * d.M * (d.N) * d.K * max(d.batch, 1), tag):
-        native.check(native.lib().dbir_gemm(ctypes.byref(d), _stream()), "dbir_gemm")
+        rc = native.lib().dbir_gemm(ctypes.byref(d), _stream())
+        if rc != 0 and from_table:  # a tuned variant whose alignment requirements this call does not meet
+            apply_tile_code(d, 0, out.device)
+            rc = native.lib().dbir_gemm(ctypes.byref(d), _stream())
+        native.check(rc, "dbir_gemm")
 
 
 def _fill_epilogue(d: GemmDesc, pw: Optional[PackedWeight], act, act_param, out_scale, residual, rowvec,
@@ -210,7 +242,7 @@ def linear(x: T, pw: PackedWeight, out: Optional[T] = None, act: int = ACT_NONE,
     d.A, d.lda = x.data_ptr(), _ld(x)
     d.W, d.Wrows, d.Kpad = pw.w.data_ptr(), pw.w.shape[0], pw.Kpad
     _fill_epilogue(d, pw, act, act_param, out_scale, residual, rowvec, rows_per_batch, out, out_f32)
-    d.tile = tile
+    apply_tile_code(d, tile, x.device)  # tile id, or tile + 100 * split-K slices
     _gemm_launch(d, (x, pw, out, residual, rowvec))
     return out
 
@@ -258,7 +290,7 @@ def conv3x3(x: T, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: boo
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo = B, Hi, Wi, Cin, Ho, Wo
     d.stride, d.pad, d.upsample = stride, pad, int(upsample)
     _fill_epilogue(d, pw, act, act_param, out_scale, residual, rowvec, Ho * Wo, out, out_f32)
-    d.tile = tile
+    apply_tile_code(d, tile, x.device)  # tile id, or tile + 100 * split-K slices
     _gemm_launch(d, (x, pw, out, residual, rowvec))
     return out
 

@@ -300,6 +300,32 @@ def test_glds_deterministic():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("code", [210, 310, 910, 212, 412, 305, 1005])
+def test_glds_splitk(code, dtype):
+    """split-K (tile + 100 * slices): f32 partial slabs + deterministic reduce kernel with the full epilogue."""
+    # conv, deep K (9 taps x 256 ch = 36 K tiles), emb row vector + residual, N % 8 == 0 but ragged vs the tile
+    x = rnd(2, 8, 8, 256, dtype=dtype)
+    pw = ops.pack_conv3x3(rnd(200, 256, 3, 3, dtype=torch.float32, s=0.02, seed=1).cpu(),
+                          rnd(200, dtype=torch.float32, seed=2).cpu(), dtype, DEV)
+    emb, res = rnd(2, 200, dtype=dtype, seed=3), rnd(2, 8, 8, 200, dtype=dtype, seed=4)
+    got = ops.conv3x3(x, pw, rowvec=emb, residual=res, act=emu.ACT_SILU, out_scale=0.7, tile=code)
+    ref = emu.conv3x3(x, pw, rowvec=emb, residual=res, act=emu.ACT_SILU, out_scale=0.7)
+    check(f"splitk conv code {code}", got, ref, dtype, scale=1.5)
+    assert torch.equal(got, ops.conv3x3(x, pw, rowvec=emb, residual=res, act=emu.ACT_SILU, out_scale=0.7, tile=code))
+    # linear into a strided output view, slices > K tiles (clamped), ragged M
+    xl = rnd(300, 192, dtype=dtype, seed=5)
+    pl = ops.pack_linear(rnd(136, 192, dtype=torch.float32, s=0.07, seed=6).cpu(), rnd(136, dtype=torch.float32, seed=7).cpu(),
+                         dtype, DEV)
+    oa = torch.zeros(300, 160, dtype=dtype, device=DEV)
+    ob = torch.zeros_like(oa)
+    ops.linear(xl, pl, out=oa[:, 8:144], tile=code)
+    emu.linear(xl, pl, out=ob[:, 8:144])
+    check(f"splitk linear code {code}", oa, ob, dtype, scale=1.5)
+    with pytest.raises(Exception):
+        ops.linear(xl, pl, tile=13 + 100 * 2)   # the phased kernel has no split-K
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_phased_gemm_race_screen(dtype):
     """Tile 13 (two staggered wave groups, counted vmcnt across barriers) at full-chip sizes, repeated, against the
     2-stage 128x128 kernel (tile 5).  Both kernels feed every output element the same MFMA sequence (K tiles in order,
