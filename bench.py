@@ -103,16 +103,27 @@ def measure_roofline(cldm, device, batch):
     torch.cuda.synchronize()
     rec = ops.stop_profile()
     tot = {}
-    for kind, flops, e0, e1, _tag in rec:
+    for kind, flops, e0, e1, _tag, nbytes in rec:
         ms = e0.elapsed_time(e1)
-        a = tot.setdefault(kind, [0.0, 0.0, 0])
+        a = tot.setdefault(kind, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += ms * 1e-3
         a[2] += 1
-    g = tot.get("gemm", [0.0, 1.0, 1])
-    out = dict(bound="mfma", kernel="gemm_kernel (implicit-GEMM conv/linear)", achieved=g[0] / g[1] / 1e12,
-               peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=g[0] / g[1] / MFMA_PEAK, traffic=None,
-               launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1], avg_launch_us=g[1] / g[2] * 1e6)
+        a[3] += nbytes
+    g = tot.get("gemm", [0.0, 1.0, 1, 0.0])
+    out = dict(bound="mfma", kernel="implicit-GEMM conv/linear family (gemm_glds_kernel / gemm_ph_kernel / gemm_kernel)",
+               achieved=g[0] / g[1] / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=g[0] / g[1] / MFMA_PEAK,
+               traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1],
+               avg_launch_us=g[1] / g[2] * 1e6, flops_per_launch=g[0] / g[2],
+               algorithmic_bytes_per_launch=g[3] / g[2])
+    # HBM bytes per GEMM launch from the rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/; FETCH_SIZE doubled
+    # per the gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE), collected on the same network evaluation
+    pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            t = json.load(f)
+        out["traffic"] = t.get("gemm_bytes_per_launch")
+        out["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     if "attention" in tot:
         a = tot["attention"]
         out["attention_kernel"] = dict(achieved=a[0] / a[1] / 1e12, frac=a[0] / a[1] / MFMA_PEAK, launches=a[2],

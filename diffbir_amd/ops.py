@@ -154,8 +154,8 @@ def stop_profile():
 class _Timed:
     """Brackets ONE kernel launch with HIP events on the current stream when profiling is on (else free)."""
 
-    def __init__(self, kind: str, flops: float, tag: str = ""):
-        self.kind, self.flops, self.tag = kind, flops, tag
+    def __init__(self, kind: str, flops: float, tag: str = "", nbytes: float = 0.0):
+        self.kind, self.flops, self.tag, self.nbytes = kind, flops, tag, nbytes
 
     def __enter__(self):
         if _PROFILE is not None:
@@ -167,7 +167,7 @@ class _Timed:
     def __exit__(self, *a):
         if _PROFILE is not None:
             self.e1.record()
-            _PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag))
+            _PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.tag, self.nbytes))
         return False
 
 
@@ -205,7 +205,13 @@ def _gemm_launch(d: GemmDesc, keep):
         tag = (f"{'conv' if d.mode == MODE_CONV3X3 else 'lin'} M{d.M} N{d.N} K{d.K} z{max(d.batch, 1)} act{d.act}"
                f"{' s2' if d.stride == 2 else ''}{' up' if d.upsample else ''}{' T' if d.store_mode else ''}"
                f"{' f32' if d.out_f32 else ''}{' res' if d.R else ''} t{d.tile}{'k%d' % d.splitk if d.splitk > 1 else ''}")
-    with _Timed("gemm", 2.0 * d.M * (d.N) * d.K * max(d.batch, 1), tag):
+    # algorithmic HBM bytes: every operand once (conv input once, not once per tap), 16-bit
+    z = max(d.batch, 1)
+    a_elems = float(d.B) * d.Hi * d.Wi * d.Cin if d.mode == MODE_CONV3X3 else float(d.M) * d.K
+    n_st = d.N // 2 if d.act == ACT_GEGLU else d.N
+    nbytes = z * (2.0 * a_elems + 2.0 * d.N * d.K + (4.0 if d.out_f32 else 2.0) * d.M * n_st
+                  + (2.0 * d.M * n_st if d.R else 0.0))
+    with _Timed("gemm", 2.0 * d.M * (d.N) * d.K * z, tag, nbytes):
         rc = native.lib().dbir_gemm(ctypes.byref(d), _stream())
         if rc != 0 and from_table:  # a tuned variant whose alignment requirements this call does not meet
             apply_tile_code(d, 0, out.device)
