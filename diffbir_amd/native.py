@@ -92,6 +92,9 @@ def lib() -> ctypes.CDLL:
         l.dbir_last_error.restype = c_char_p
         l.dbir_last_error.argtypes = []
         _lib = l
+        v = os.environ.get("DBIR_ATTN_VARIANT")  # A/B switch (include/dbir.h DBIR_OPT_ATTN_VARIANT)
+        if v:
+            check(l.dbir_set_option(1, int(v)), "dbir_set_option")
     return _lib
 
 

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--tiles", default="1,5,6,7")
     ap.add_argument("--only", default="")
+    ap.add_argument("--attn-variants", default="2", help="comma list of attention kernel variants to time")
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(",")]
     rows = []
@@ -109,8 +110,12 @@ def main():
             lkp = (lk + 7) // 8 * 8
             vt = rnd(b, C, lkp)
             o = torch.empty(b, lq, C, dtype=DT, device=DEV)
-            sec = timeit(lambda: ops.attention(q, k, vt, o, hds, lk, 0.125))
-            report(f"attention B{b} H{hds} Lq{lq} Lk{lk}", "flash", sec, flops=4.0 * b * hds * lq * lk * 64)
+            from diffbir_amd import native
+            for v in [int(x) for x in args.attn_variants.split(",")]:
+                native.check(native.lib().dbir_set_option(1, v), "dbir_set_option")
+                sec = timeit(lambda: ops.attention(q, k, vt, o, hds, lk, 0.125))
+                report(f"attention B{b} H{hds} Lq{lq} Lk{lk}", f"v{v}", sec, flops=4.0 * b * hds * lq * lk * 64)
+            native.check(native.lib().dbir_set_option(1, 2), "dbir_set_option")
     if want("norm"):
         for (b, hw, c) in [(B, 4096, 320), (B, 4096, 960), (B, 1024, 640), (B, 256, 1280), (B, 64, 2560),
                            (8, 262144, 128)]:
