@@ -302,13 +302,14 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 13, "dbir_gemm: bad tile %d", tile);
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 16, "dbir_gemm: bad tile %d", tile);
   if (tile == 0 || tile >= 5) {
     const bool ok = dbir_gemm_glds_eligible(d);
     DBIR_CHECK_ARG(ok || tile == 0, "dbir_gemm: tile %d (direct-to-LDS kernel) needs K/Cin %% 64 == 0, 16-byte aligned "
                    "operands and a 16-bit row-major output", tile);
     DBIR_CHECK_ARG(d.splitk <= 1 || (ok && tile != 13), "dbir_gemm: split-K is implemented by the direct-to-LDS "
                    "kernel only (tiles 5-12, eligible operands)");
+    DBIR_CHECK_ARG(!(tile == 13 && d.store_mode != 0), "dbir_gemm: the phased kernel (tile 13) has no transposed store");
     if (ok && tile == 13) return dbir_gemm_ph(d, p.Hv, p.Wv, reinterpret_cast<hipStream_t>(stream));
     if (ok) return dbir_gemm_glds(d, p.Hv, p.Wv, tile, reinterpret_cast<hipStream_t>(stream));
   }

@@ -74,10 +74,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int RPP = NT / 8;                  // tile rows covered by one glds pass of the whole block
   constexpr int PASS_BYTES = NT * 16;
-  constexpr int RA = BM / RPP, RB = BN / RPP;  // glds per thread per stage for the activation / weight tile
+  constexpr int RA = BM / RPP, RB = (BN + RPP - 1) / RPP;  // glds per thread per stage (activation / weight tile)
   constexpr int LOADS = RA + RB;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
-  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the pass height");
+  // BN = 160 (NJ = 5) is not a multiple of the pass height: the weight region is rounded up to whole passes and the
+  // rows past BN are fed from the zero page
+  constexpr int A_BYTES = BM * 128, B_BYTES = RB * RPP * 128, BUF_BYTES = A_BYTES + B_BYTES;
+  static_assert(BM % RPP == 0, "activation tile rows must be a multiple of the pass height");
   static_assert(STAGES >= 2 && (STAGES - 1) * LOADS < 64, "vmcnt is 6 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int n = tn * BN + srow + RPP * i;
-    w_rv[i] = n < d.Wrows;
+    w_rv[i] = n < d.Wrows && srow + RPP * i < BN;
     w_rp[i] = w_rv[i] ? Wg + (long long)n * d.Kpad + cch : zp;
   }
 
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * d.act_param;
         } else if (geglu) {
-          if constexpr (NJ >= 2) {
+          if constexpr (NJ == 2) {
             constexpr int JG = 1;  // gate tile of this value tile (NJ == 2: tiles are (value, gate))
             const float gt[4] = {acc[i][JG][4 * g + 0] + b4[JG][g].x, acc[i][JG][4 * g + 1] + b4[JG][g].y,
                                  acc[i][JG][4 * g + 2] + b4[JG][g].z, acc[i][JG][4 * g + 3] + b4[JG][g].w};
@@ -348,6 +350,36 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     }
   }
   __syncthreads();
+  if (d.store_mode == 1) {
+    // transposed per-batch store  C[(m / L) * bstride + n * trans_ld + (m % L)]  (V^T for the attention kernel):
+    // one thread = 8 consecutive rows m of one column n -> one 16-byte store; consecutive lanes take consecutive
+    // columns, so the 2-byte LDS reads are conflict-free (L % 8 == 0 keeps a chunk inside one batch).
+    u16* __restrict__ Ct = reinterpret_cast<u16*>(d.C);
+    const int total = (BM / 8) * bn_out;
+    for (int q = tid; q < total; q += NT) {
+      const int mc = q / bn_out, nl = q - mc * bn_out;
+      const int m0 = tm * BM + mc * 8, n = tn * bn_out + nl;
+      if (m0 >= M || n >= N) continue;
+      u16 hv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hv[e] = Cs[(mc * 8 + e) * cs_ld + nl];
+      const int bb = m0 / d.trans_L, l0 = m0 - bb * d.trans_L;
+      u16* dst = Ct + (long long)bb * d.trans_bstride + (long long)n * d.trans_ld + l0;
+      if (m0 + 8 <= M) {
+        uint4 v;
+        v.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+        v.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+        v.z = (uint32_t)hv[4] | ((uint32_t)hv[5] << 16);
+        v.w = (uint32_t)hv[6] | ((uint32_t)hv[7] << 16);
+        *reinterpret_cast<uint4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (m0 + e < M) dst[e] = hv[e];
+      }
+    }
+    return;
+  }
   {
     const int n_out = geglu ? N / 2 : N;
     const int ch_per_row = bn_out >> 3;
@@ -442,7 +474,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
 template <typename T, int WM, int WN, int MI, int NJ, int STAGES>
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-  constexpr int ring = STAGES * (BM + BN) * 128, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
+  constexpr int RPP_ = 8 * WM * WN, BNR = (BN + RPP_ - 1) / RPP_ * RPP_;
+  constexpr int ring = STAGES * (BM + BNR) * 128, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
   constexpr int lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   constexpr int blocks_per_cu = (160 * 1024) / lds;
@@ -480,6 +513,9 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
     case 10: return launch2<T, 2, 4, 4, 2, 2>(p, s);  // 256x256, 8 waves (128x64 each), 2 stages
     case 11: return launch2<T, 2, 2, 2, 2, 4>(p, s);  // 128x128, 4 waves, 4 stages, 1 block / CU
     case 12: return launch2<T, 4, 2, 2, 2, 2>(p, s);  // 256x128, 8 waves, 2 stages
+    case 14: return launch2<T, 8, 1, 1, 5, 2>(p, s);  // 256x160, 8 waves (32x160 each): N = 320 k without padding
+    case 15: return launch2<T, 4, 1, 1, 5, 2>(p, s);  // 128x160, 4 waves, 2 blocks / CU
+    case 16: return launch2<T, 4, 1, 2, 5, 2>(p, s);  // 256x160, 4 waves (64x160 each)
   }
   dbir_set_error("dbir_gemm: bad glds tile %d", tile);
   return DBIR_ERR_ARG;
@@ -489,7 +525,14 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
 
 // Is the descriptor (already validated by dbir_gemm) runnable on the direct-to-LDS kernel?
 bool dbir_gemm_glds_eligible(const dbir_gemm_desc& d) {
-  if (d.store_mode != 0 || d.out_f32) return false;
+  if (d.out_f32) return false;
+  if (d.store_mode == 1) {  // transposed store: whole 8-row chunks inside one batch, 16-byte aligned destinations
+    if (d.trans_L % 8 != 0 || d.trans_ld % 8 != 0 || d.trans_bstride % 8 != 0 || d.R || d.act == DBIR_ACT_GEGLU ||
+        d.splitk > 1 || d.batch > 1)
+      return false;
+  } else if (d.store_mode != 0) {
+    return false;
+  }
   if (d.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(d.C) & 15)) return false;
   if (d.R && (d.ldr % 8 != 0 || (reinterpret_cast<uintptr_t>(d.R) & 15))) return false;
   if ((reinterpret_cast<uintptr_t>(d.A) & 15) || (reinterpret_cast<uintptr_t>(d.W) & 15)) return false;
@@ -553,6 +596,10 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
       tile = 12;
     else
       tile = 5;
+  }
+  if (dd.act == DBIR_ACT_GEGLU && tile >= 14) {
+    dbir_set_error("dbir_gemm: GEGLU needs a tile whose waves hold value/gate column pairs (tiles 5-13)");
+    return DBIR_ERR_ARG;
   }
   return dd.dtype == DBIR_F16 ? dispatch2<F16>(p, tile, s) : dispatch2<BF16>(p, tile, s);
 }

@@ -196,7 +196,7 @@ def apply_tile_code(d: GemmDesc, code: int, device) -> None:
 def _gemm_launch(d: GemmDesc, keep):
     out = keep[2]
     from_table = False
-    if d.tile == 0 and d.store_mode == 0 and not d.out_f32:
+    if d.tile == 0 and not d.out_f32:
         code = _TUNER.run(d, out) if _TUNER is not None else tuning.lookup(d)
         from_table = code != 0
         apply_tile_code(d, code, out.device)
@@ -253,7 +253,7 @@ def linear(x: T, pw: PackedWeight, out: Optional[T] = None, act: int = ACT_NONE,
     return out
 
 
-def linear_t(x: T, pw: PackedWeight, L: int, out_t: T) -> T:
+def linear_t(x: T, pw: PackedWeight, L: int, out_t: T, tile: int = 0) -> T:
     """Transposed store: out_t[b, n, l] = (x @ W^T)[b*L + l, n] for x: [Bz*L, K]; out_t: [Bz, N, Lpad] 16-bit."""
     _gpu(x, out_t)
     M, K = _rows(x), x.shape[-1]
@@ -268,6 +268,7 @@ def linear_t(x: T, pw: PackedWeight, L: int, out_t: T) -> T:
     d.C, d.ldc = out_t.data_ptr(), 0
     d.store_mode, d.trans_L, d.trans_ld, d.trans_bstride = 1, L, out_t.stride(1), out_t.stride(0)
     d.batch = 1
+    d.tile = tile
     _gemm_launch(d, (x, pw, out_t))
     return out_t
 

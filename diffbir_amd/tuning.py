@@ -18,7 +18,7 @@ _table: Optional[Dict[str, int]] = None
 def key_of(d) -> str:
     """Problem key of a GemmDesc: everything that changes which tile wins."""
     return (f"{d.mode}:{d.M}:{d.N}:{d.K}:a{d.act}:s{d.stride}:u{d.upsample}:z{max(d.batch, 1)}:"
-            f"r{1 if d.R else 0}:v{1 if d.rowvec else 0}")
+            f"r{1 if d.R else 0}:v{1 if d.rowvec else 0}{':T' if d.store_mode else ''}")
 
 
 def load(path: Optional[str] = None) -> Dict[str, int]:

@@ -65,7 +65,7 @@ def linear(x, pw, out=None, act=ACT_NONE, act_param=0.0, out_scale=1.0, residual
     return out
 
 
-def linear_t(x, pw, L, out_t):
+def linear_t(x, pw, L, out_t, tile=0):
     K = x.shape[-1]
     acc = x.reshape(-1, K).float() @ pw.w[: pw.N, :K].float().t()
     if pw.bias is not None:

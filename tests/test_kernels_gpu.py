@@ -187,7 +187,8 @@ def test_conv3x3_fused_epilogue(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
-GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13]
+GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
+NO_GEGLU_TILES = (14, 15, 16)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -228,11 +229,34 @@ def test_glds_geglu(M, Nh, K, tile, dtype):
     x = rnd(M, K, dtype=dtype)
     w, b = rnd(2 * Nh, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(2 * Nh, dtype=torch.float32, seed=2)
     pw = ops.pack_geglu(w.cpu(), b.cpu(), dtype, DEV)
+    if tile in NO_GEGLU_TILES:
+        with pytest.raises(Exception):
+            ops.linear(x, pw, tile=tile)
+        return
     h = x.float() @ w.to(dtype).float().t() + b
     ref = (h[:, :Nh] * torch.nn.functional.gelu(h[:, Nh:])).to(dtype)
     check(f"glds geglu {M}x{Nh}x{K} t{tile}", ops.linear(x, pw, tile=tile), ref, dtype)
     res = rnd(M, Nh, dtype=dtype, seed=5)
     check("glds geglu+res", ops.linear(x, pw, residual=res, tile=tile), emu.linear(x, pw, residual=res), dtype, 1.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", GLDS_TILES)
+@pytest.mark.parametrize("Bz,L,N,K", [(2, 64, 128, 64), (2, 1024, 640, 640), (3, 200, 320, 320), (1, 4096, 320, 320)])
+def test_glds_linear_transposed(Bz, L, N, K, tile, dtype):
+    """transposed per-batch store (V^T for the attention kernel) from the direct-to-LDS kernels' LDS-staged epilogue."""
+    x = rnd(Bz * L, K, dtype=dtype)
+    w, bias = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), bias.cpu(), dtype, DEV)
+    a = torch.zeros(Bz, N + 3, L + 16, dtype=dtype, device=DEV)[:, :N]     # padded rows / batch stride
+    b = torch.zeros(Bz, N + 3, L + 16, dtype=dtype, device=DEV)[:, :N]
+    if tile == 13:
+        with pytest.raises(Exception):
+            ops.linear_t(x, pw, L, a, tile=tile)
+        return
+    ops.linear_t(x, pw, L, a, tile=tile)
+    emu.linear_t(x, pw, L, b)
+    check(f"glds linear_t {Bz}x{L}x{N}x{K} t{tile}", a, b, dtype)
 
 
 GLDS_CONV_CASES = [

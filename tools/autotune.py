@@ -18,8 +18,9 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from diffbir_amd import native, ops, tuning  # noqa: E402
 
-CANDIDATES = [5, 6, 7, 8, 9, 10, 11, 12, 13]          # tile ids (include/dbir.h)
-SPLITK = [(10, 2), (10, 3), (10, 4), (10, 6), (10, 9), (12, 2), (12, 3), (12, 4), (5, 2), (5, 3)]  # (tile, slices)
+CANDIDATES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]   # tile ids (include/dbir.h)
+SPLITK = [(10, 2), (10, 3), (10, 4), (10, 6), (10, 9), (12, 2), (12, 3), (12, 4), (5, 2), (5, 3), (14, 2), (14, 3), (14, 4),
+          (15, 2), (15, 3)]  # (tile, slices)
 
 
 class Tuner:
@@ -65,7 +66,7 @@ class Tuner:
         cands = list(self.cands)
         # split-K only where the output tiles alone cannot fill the chip and K is deep (16x16 / 8x8 latent levels)
         if (d.M * d.N <= 160 * 256 * 256 and d.K >= 1280 and d.N % 8 == 0 and d.act != ops.ACT_GEGLU
-                and "splitk" not in self.exclude):
+                and d.store_mode == 0 and "splitk" not in self.exclude):
             cands += [t + 100 * k for t, k in SPLITK if t not in self.exclude]
         for c in cands:
             ops.apply_tile_code(d, c, out.device)
