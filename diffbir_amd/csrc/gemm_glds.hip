@@ -68,7 +68,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW>
+// PIPE = 1: the MFMA fragments of k-step ks+1 are read from LDS BEFORE the MFMAs of k-step ks are issued (two
+// register sets), so the ds_read latency of all but a K tile's first k-step hides under the matrix pipe; with
+// PIPE = 0 the compiler emits read -> s_waitcnt lgkmcnt(0) -> MFMA per k-step and the two waves of a SIMD, which run
+// in lockstep, expose that latency together (rocprofv3: 35 % MFMA utilisation, 43 % of wave cycles in s_waitcnt).
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2Params p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
@@ -223,23 +227,52 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       wait_vmcnt<0>();
     // every wave's share landed, and everyone is done reading the slot that is refilled next
     asm volatile("s_barrier" ::: "memory");
-    if (kt + STAGES - 1 < nk) STAGE();
     const char* base = smem + c_slot * BUF_BYTES;
     c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
+    if constexpr (!PIPE) {
+      if (kt + STAGES - 1 < nk) STAGE();
+    }
+    if constexpr (PIPE) {
+      typename T::vec8 xf[2][MI], wf[2][NJ];
+#define LOAD_FRAGS(KS, SET)                                                                                   \
+  do {                                                                                                        \
+    const int co_ = ((2 * (KS) + hi) ^ sw) * 16;                                                              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) wf[SET][j] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * 4096 + co_);                           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) xf[SET][i] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co_);                           \
+  } while (0)
+      LOAD_FRAGS(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the next tile's direct-to-LDS loads are issued while the first fragment reads are in flight (the slot they
+      // refill was last read before the barrier above)
+      if (kt + STAGES - 1 < nk) STAGE();
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int co = ((2 * ks + hi) ^ sw) * 16;
-      typename T::vec8 xf[MI], wf[NJ];
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) LOAD_FRAGS(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's reads ahead of this k-step's MFMAs
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        wf[j] = *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * 4096 + co);
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        xf[i] = *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co);
+          for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[ks & 1][j], xf[ks & 1][i], acc[i][j]);  // D[n][m]
+      }
+#undef LOAD_FRAGS
+    } else {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int ks = 0; ks < 4; ++ks) {
+        const int co = ((2 * ks + hi) ^ sw) * 16;
+        typename T::vec8 xf[MI], wf[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);  // D[n][m]
+        for (int j = 0; j < NJ; ++j)
+          wf[j] = *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * 4096 + co);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          xf[i] = *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);  // D[n][m]
+      }
     }
   }
 #undef STAGE
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
   }
 }
 
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES>
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0>
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int RPP_ = 8 * WM * WN, BNR = (BN + RPP_ - 1) / RPP_ * RPP_;
@@ -481,7 +514,7 @@ int launch2(G2Params& p, hipStream_t s) {
   constexpr int blocks_per_cu = (160 * 1024) / lds;
   constexpr int waves = WM * WN * (blocks_per_cu > 2 ? 2 : blocks_per_cu);
   constexpr int MINW = waves >= 8 ? 2 : 1;
-  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW>;
+  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -516,6 +549,13 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
     case 14: return launch2<T, 8, 1, 1, 5, 2>(p, s);  // 256x160, 8 waves (32x160 each): N = 320 k without padding
     case 15: return launch2<T, 4, 1, 1, 5, 2>(p, s);  // 128x160, 4 waves, 2 blocks / CU
     case 16: return launch2<T, 4, 1, 2, 5, 2>(p, s);  // 256x160, 4 waves (64x160 each)
+    // 20 + t: tile t with software-pipelined fragment reads (PIPE = 1)
+    case 25: return launch2<T, 2, 2, 2, 2, 2, 1>(p, s);
+    case 26: return launch2<T, 4, 1, 2, 2, 2, 1>(p, s);
+    case 30: return launch2<T, 2, 4, 4, 2, 2, 1>(p, s);
+    case 32: return launch2<T, 4, 2, 2, 2, 2, 1>(p, s);
+    case 34: return launch2<T, 8, 1, 1, 5, 2, 1>(p, s);
+    case 35: return launch2<T, 4, 1, 1, 5, 2, 1>(p, s);
   }
   dbir_set_error("dbir_gemm: bad glds tile %d", tile);
   return DBIR_ERR_ARG;
@@ -597,7 +637,7 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
     else
       tile = 5;
   }
-  if (dd.act == DBIR_ACT_GEGLU && tile >= 14) {
+  if (dd.act == DBIR_ACT_GEGLU && (tile == 14 || tile == 15 || tile == 16 || tile == 34 || tile == 35)) {
     dbir_set_error("dbir_gemm: GEGLU needs a tile whose waves hold value/gate column pairs (tiles 5-13)");
     return DBIR_ERR_ARG;
   }

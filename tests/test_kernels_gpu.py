@@ -187,8 +187,8 @@ def test_conv3x3_fused_epilogue(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
-GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
-NO_GEGLU_TILES = (14, 15, 16)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
+GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 25, 26, 30, 32, 34, 35]   # 20 + t: pipelined fragment reads
+NO_GEGLU_TILES = (14, 15, 16, 34, 35)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
