@@ -26,6 +26,8 @@
 //     stores (+ residual add on that side).
 //   * blockIdx -> tile mapping is XCD-aware (bijective remap, guide T1): each XCD's L2 sees a contiguous
 //     range of tiles with the N tiles of one activation panel adjacent.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -43,6 +45,8 @@ struct G2Params {
   int vec_bias, vec_rv;  // bias / row vector may be read with 16 B / 8 B vector loads
   int splitk, kt_per;    // split-K: number of K slices (1 = off) and K tiles per slice
   float* ws;             // split-K: f32 partial sums [z][slice][M][N]
+  int tap_inner;         // conv K order: 1 = (channel tile, tap), 0 = (tap, channel tile)
+  int debug;             // DIAGNOSTIC (env DBIR_GEMM_DEBUG): 1 = skip steady-state staging, 2 = skip MFMAs
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -116,30 +120,40 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   const int cch = ((tid & 7) ^ ((srow >> 1) & 7)) * 8;  // logical K offset (halfs) of the chunk this thread fetches
   const bool conv = d.mode == DBIR_MODE_CONV3X3;
 
-  int a_pix0[RA];       // conv: b*Hi*Wi
-  int a_yx0[RA];        // conv: iy0 * 65536 + (ix0 & 0xffff), virtual coords of tap (0,0)
-  bool a_ok[RA];        // row < M
-  const u16* a_rp[RA];  // current row pointer (tap applied); zero page when invalid
-  bool a_rv[RA];
+  // Activation rows: pointer to the element of tap (0,0) (never dereferenced when that tap is outside the image) and
+  // a 9-bit tap validity mask; for a nearest-x2 upsampled input bits 16/17 hold the x/y parity that decides whether
+  // tap k moves to the next source pixel ((k + parity) >> 1).  The per-K-tile source address is then
+  // a_base[i] + <scalar offset of (tap, channel tile)>: no per-tap re-derivation of coordinates.
+  const u16* a_base[RA];
+  unsigned a_mask[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = tm * BM + srow + RPP * i;
-    a_ok[i] = m < M;
+    const bool ok = m < M;
     if (conv) {
       const int hw = d.Ho * d.Wo;
-      const int mm = a_ok[i] ? m : 0;
+      const int mm = ok ? m : 0;
       const int b = mm / hw;
       const int rem = mm - b * hw;
       const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
-      a_pix0[i] = b * d.Hi * d.Wi;
-      a_yx0[i] = (oy * d.stride - d.pad) * 65536 + ((ox * d.stride - d.pad) & 0xffff);
-      a_rp[i] = zp;
-      a_rv[i] = false;
+      const int iy0 = oy * d.stride - d.pad, ix0 = ox * d.stride - d.pad;  // virtual coords of tap (0,0)
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+        if (ok && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv) mk |= 1u << t;
+      }
+      int sy = iy0, sx = ix0;
+      if (d.upsample) {
+        mk |= (unsigned)(ix0 & 1) << 16 | (unsigned)(iy0 & 1) << 17;
+        sy >>= 1;  // arithmetic shift: -1 -> -1 (masked)
+        sx >>= 1;
+      }
+      a_mask[i] = mk;
+      a_base[i] = Ag + ((long long)b * d.Hi * d.Wi + (long long)sy * d.Wi + sx) * d.Cin + cch;
     } else {
-      a_pix0[i] = 0;
-      a_yx0[i] = 0;
-      a_rv[i] = a_ok[i];
-      a_rp[i] = a_ok[i] ? Ag + (long long)m * d.lda + cch : zp;
+      a_mask[i] = ok ? 1u : 0u;
+      a_base[i] = Ag + (long long)(ok ? m : 0) * d.lda + cch;
     }
   }
   const u16* w_rp[RB];
@@ -151,51 +165,53 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     w_rp[i] = w_rv[i] ? Wg + (long long)n * d.Kpad + cch : zp;
   }
 
-  // staging cursor (uniform): tile index, tap, channel-tile within the tap, ring slot.  With split-K this block owns
-  // K tiles [kt0, kt0 + nk).
+  // staging cursor (uniform): K tile, tap, channel tile, ring slot.  K tiles are visited TAP-INNER for convolutions
+  // (p.tap_inner): the 9 taps of one 64-channel slice are consecutive, so a block re-reads the same few image rows
+  // of that slice from L2 nine times instead of streaming its whole activation panel once per tap (rocprofv3: L2 hit
+  // rate 74 % -> see profiles/).  With split-K this block owns K tiles [kt0, kt0 + nk).
   const int kt0 = ksp * p.kt_per;
-  int s_kt = kt0, s_tap = kt0 / p.nkc, s_slot = 0;
-  int s_cc = kt0 - s_tap * p.nkc;
-
-#define SET_TAP()                                                                                   \
-  do {                                                                                              \
-    if (conv) {                                                                                     \
-      const int ky_ = (s_tap * 11) >> 5, kx_ = s_tap - 3 * ky_;                                     \
-      _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                              \
-        int iy_ = (a_yx0[i] >> 16) + ky_;                                                           \
-        int ix_ = (int)(short)(a_yx0[i] & 0xffff) + kx_;                                            \
-        const bool ok_ = a_ok[i] && iy_ >= 0 && iy_ < p.Hv && ix_ >= 0 && ix_ < p.Wv;               \
-        if (d.upsample) {                                                                           \
-          iy_ >>= 1;                                                                                \
-          ix_ >>= 1;                                                                                \
-        }                                                                                           \
-        a_rv[i] = ok_;                                                                              \
-        a_rp[i] = ok_ ? Ag + (long long)(a_pix0[i] + iy_ * d.Wi + ix_) * d.Cin + cch : zp;          \
-      }                                                                                             \
-    }                                                                                               \
-  } while (0)
+  int s_kt = kt0, s_slot = 0, s_tap, s_cc;
+  if (p.tap_inner) {
+    s_cc = kt0 / p.ntaps;
+    s_tap = kt0 - s_cc * p.ntaps;
+  } else {
+    s_tap = kt0 / p.nkc;
+    s_cc = kt0 - s_tap * p.nkc;
+  }
 
 // issue the direct-to-LDS loads of K tile s_kt into ring slot s_slot, then advance the cursor
 #define STAGE()                                                                                     \
   do {                                                                                              \
     char* ab_ = smem + s_slot * BUF_BYTES + wave * 1024;                                            \
     char* bb_ = ab_ + A_BYTES;                                                                      \
-    const int koff_ = s_cc * BK;                                                                    \
+    const int ky_ = (s_tap * 11) >> 5, kx_ = s_tap - 3 * ky_;                                       \
+    const long long aoff_ = (long long)(ky_ * d.Wi + kx_) * d.Cin + s_cc * BK;                      \
     _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                                \
-      const u16* src_ = a_rv[i] ? a_rp[i] + koff_ : zp;                                             \
+      long long o_ = aoff_;                                                                         \
+      if (d.upsample) {                                                                             \
+        const int dy_ = (ky_ + (int)((a_mask[i] >> 17) & 1)) >> 1;                                  \
+        const int dx_ = (kx_ + (int)((a_mask[i] >> 16) & 1)) >> 1;                                  \
+        o_ = (long long)(dy_ * d.Wi + dx_) * d.Cin + s_cc * BK;                                     \
+      }                                                                                             \
+      const bool v_ = ((a_mask[i] >> s_tap) & 1u) && p.debug != 3;                                  \
+      const u16* src_ = v_ ? a_base[i] + o_ : zp;                                                   \
       __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(ab_ + i * PASS_BYTES), 16, 0, 0);     \
     }                                                                                               \
-    const long long woff_ = (long long)s_kt * BK;                                                   \
+    const long long woff_ = (long long)(s_tap * p.nkc + s_cc) * BK;                                 \
     _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                \
-      const u16* src_ = w_rv[i] ? w_rp[i] + woff_ : zp;                                             \
+      const u16* src_ = (w_rv[i] && p.debug != 3) ? w_rp[i] + woff_ : zp;                           \
       __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(bb_ + i * PASS_BYTES), 16, 0, 0);     \
     }                                                                                               \
     ++s_kt;                                                                                         \
     s_slot = (s_slot + 1 == STAGES) ? 0 : s_slot + 1;                                               \
-    if (++s_cc == p.nkc) {                                                                          \
+    if (p.tap_inner) {                                                                              \
+      if (++s_tap == p.ntaps) {                                                                     \
+        s_tap = 0;                                                                                  \
+        ++s_cc;                                                                                     \
+      }                                                                                             \
+    } else if (++s_cc == p.nkc) {                                                                   \
       s_cc = 0;                                                                                     \
       ++s_tap;                                                                                      \
-      if (s_tap < p.ntaps) SET_TAP();                                                               \
     }                                                                                               \
   } while (0)
 
@@ -208,7 +224,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (p.nkc * p.ntaps - kt0 < p.kt_per) ? p.nkc * p.ntaps - kt0 : p.kt_per;
-  SET_TAP();
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) STAGE();
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     const char* base = smem + c_slot * BUF_BYTES;
     c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
     if constexpr (!PIPE) {
-      if (kt + STAGES - 1 < nk) STAGE();
+      if (kt + STAGES - 1 < nk && p.debug != 1) STAGE();
     }
     if constexpr (PIPE) {
       typename T::vec8 xf[2][MI], wf[2][NJ];
@@ -246,7 +261,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       __builtin_amdgcn_sched_barrier(0);
       // the next tile's direct-to-LDS loads are issued while the first fragment reads are in flight (the slot they
       // refill was last read before the barrier above)
-      if (kt + STAGES - 1 < nk) STAGE();
+      if (kt + STAGES - 1 < nk && p.debug != 1) STAGE();
+      if (p.debug == 2) continue;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks < 3) LOAD_FRAGS(ks + 1, (ks + 1) & 1);
@@ -258,6 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       }
 #undef LOAD_FRAGS
     } else {
+      if (p.debug == 2) continue;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int co = ((2 * ks + hi) ^ sw) * 16;
@@ -276,7 +293,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     }
   }
 #undef STAGE
-#undef SET_TAP
 
   const int N = d.N;
   if (p.splitk > 1) {
@@ -601,6 +617,12 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
   }
   p.vec_bias = dd.bias && (reinterpret_cast<uintptr_t>(dd.bias) & 15) == 0;
   p.vec_rv = dd.rowvec && (reinterpret_cast<uintptr_t>(dd.rowvec) & 7) == 0 && dd.rowvec_ld % 4 == 0;
+  {
+    static const int dbg = getenv("DBIR_GEMM_DEBUG") ? atoi(getenv("DBIR_GEMM_DEBUG")) : 0;
+    static const int tap_inner = getenv("DBIR_TAP_INNER") ? atoi(getenv("DBIR_TAP_INNER")) : 1;  // A/B switch
+    p.debug = dbg;
+    p.tap_inner = tap_inner;
+  }
   {
     // split-K (explicit request only): slices of whole K tiles; every slice must be non-empty
     const int nk_total = p.nkc * p.ntaps;

@@ -28,6 +28,8 @@
 //   RAW  every wave waits `vmcnt(8)` (the 4 most recent half tiles may stay in flight) BEFORE the first barrier of
 //        the phase preceding the first read of the half tile that the wait retires; loads past the last K tile are
 //        issued from a zero page into (free) slots so the count is the same in every phase.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -48,6 +50,7 @@ struct PhParams {
   int nkc, ntaps;
   int mtiles, ntiles;
   int vec_bias, vec_rv;
+  int tap_inner;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -114,28 +117,38 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
   // ---- staging roles: LDS row rho = srow + 64*j (j = 0..3; j>>1 = half), chunk position tid&7 ----
   const int srow = tid >> 3;
   const int cch = ((tid & 7) ^ ((srow >> 1) & 7)) * 8;  // logical K offset (halfs) fetched by this thread
-  int a_pix0[4], a_yx0[4];
-  bool a_ok[4], a_rv[4];
-  const u16* a_rp[4];
+  // activation rows: pointer to the element of tap (0,0) + 9-bit tap validity mask (+ x/y parity bits 16/17 for the
+  // nearest-x2 upsampled input) — same scheme as gemm_glds.hip
+  const u16* a_base[4];
+  unsigned a_mask[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = tm * PBM + srow + 64 * j;
-    a_ok[j] = m < M;
+    const bool ok = m < M;
     if (conv) {
       const int hw = d.Ho * d.Wo;
-      const int mm = a_ok[j] ? m : 0;
+      const int mm = ok ? m : 0;
       const int b = mm / hw;
       const int rem = mm - b * hw;
       const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
-      a_pix0[j] = b * d.Hi * d.Wi;
-      a_yx0[j] = (oy * d.stride - d.pad) * 65536 + ((ox * d.stride - d.pad) & 0xffff);
-      a_rp[j] = zp;
-      a_rv[j] = false;
+      const int iy0 = oy * d.stride - d.pad, ix0 = ox * d.stride - d.pad;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+        if (ok && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv) mk |= 1u << t;
+      }
+      int sy = iy0, sx = ix0;
+      if (d.upsample) {
+        mk |= (unsigned)(ix0 & 1) << 16 | (unsigned)(iy0 & 1) << 17;
+        sy >>= 1;
+        sx >>= 1;
+      }
+      a_mask[j] = mk;
+      a_base[j] = Ag + ((long long)b * d.Hi * d.Wi + (long long)sy * d.Wi + sx) * d.Cin + cch;
     } else {
-      a_pix0[j] = 0;
-      a_yx0[j] = 0;
-      a_rv[j] = a_ok[j];
-      a_rp[j] = a_ok[j] ? Ag + (long long)m * d.lda + cch : zp;
+      a_mask[j] = ok ? 1u : 0u;
+      a_base[j] = Ag + (long long)(ok ? m : 0) * d.lda + cch;
     }
   }
   const u16* w_rp[4];
@@ -148,61 +161,59 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
     w_rp[j] = w_rv[j] ? Wg + (long long)n * d.Kpad + cch : zp;
   }
 
-  // per-half activation cursors (K tile, tap, channel tile within the tap)
-  int a_kt[2] = {0, 0}, a_tap[2] = {0, 0}, a_cc[2] = {0, 0};
+  // per-half-tile cursors (K tile, tap, channel tile); K tiles are visited tap-inner for convolutions (p.tap_inner,
+  // see gemm_glds.hip).  Index 0/1 = activation lo/hi, 2/3 = weight lo/hi.
+  int c_kt[4] = {0, 0, 0, 0}, c_tap[4] = {0, 0, 0, 0}, c_cc[4] = {0, 0, 0, 0};
 
-#define PH_SET_TAP(H)                                                                             \
-  do {                                                                                            \
-    if (conv) {                                                                                   \
-      const int ky_ = (a_tap[H] * 11) >> 5, kx_ = a_tap[H] - 3 * ky_;                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                          \
-        const int j_ = 2 * (H) + i_;                                                              \
-        int iy_ = (a_yx0[j_] >> 16) + ky_;                                                        \
-        int ix_ = (int)(short)(a_yx0[j_] & 0xffff) + kx_;                                         \
-        const bool ok_ = a_ok[j_] && iy_ >= 0 && iy_ < p.Hv && ix_ >= 0 && ix_ < p.Wv;            \
-        if (d.upsample) {                                                                         \
-          iy_ >>= 1;                                                                              \
-          ix_ >>= 1;                                                                              \
-        }                                                                                         \
-        a_rv[j_] = ok_;                                                                           \
-        a_rp[j_] = ok_ ? Ag + (long long)(a_pix0[j_] + iy_ * d.Wi + ix_) * d.Cin + cch : zp;      \
-      }                                                                                           \
-    }                                                                                             \
+#define PH_ADVANCE(C)                    \
+  do {                                   \
+    ++c_kt[C];                           \
+    if (p.tap_inner) {                   \
+      if (++c_tap[C] == p.ntaps) {       \
+        c_tap[C] = 0;                    \
+        ++c_cc[C];                       \
+      }                                  \
+    } else if (++c_cc[C] == p.nkc) {     \
+      c_cc[C] = 0;                       \
+      ++c_tap[C];                        \
+    }                                    \
   } while (0)
 
 // stage the next K tile of activation half H into buffer BUFI (0/1), then advance that half's cursor
 #define PH_STAGE_A(H, BUFI)                                                                       \
   do {                                                                                            \
     char* dst_ = smem + (BUFI) * BUF_BYTES + (H) * HALF_BYTES + wave * 1024;                      \
-    const bool live_ = a_kt[H] < nk;                                                              \
-    const int koff_ = a_cc[H] * BK;                                                               \
+    const bool live_ = c_kt[H] < nk;                                                              \
+    const int tap_ = c_tap[H];                                                                    \
+    const int ky_ = (tap_ * 11) >> 5, kx_ = tap_ - 3 * ky_;                                       \
+    const long long aoff_ = (long long)(ky_ * d.Wi + kx_) * d.Cin + c_cc[H] * BK;                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                            \
       const int j_ = 2 * (H) + i_;                                                                \
-      const u16* src_ = (live_ && a_rv[j_]) ? a_rp[j_] + koff_ : zp;                              \
+      long long o_ = aoff_;                                                                       \
+      if (d.upsample) {                                                                           \
+        const int dy_ = (ky_ + (int)((a_mask[j_] >> 17) & 1)) >> 1;                               \
+        const int dx_ = (kx_ + (int)((a_mask[j_] >> 16) & 1)) >> 1;                               \
+        o_ = (long long)(dy_ * d.Wi + dx_) * d.Cin + c_cc[H] * BK;                                \
+      }                                                                                           \
+      const bool v_ = live_ && ((a_mask[j_] >> tap_) & 1u);                                       \
+      const u16* src_ = v_ ? a_base[j_] + o_ : zp;                                                \
       __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(dst_ + i_ * 8192), 16, 0, 0);       \
     }                                                                                             \
-    if (live_) {                                                                                  \
-      ++a_kt[H];                                                                                  \
-      if (++a_cc[H] == p.nkc) {                                                                   \
-        a_cc[H] = 0;                                                                              \
-        ++a_tap[H];                                                                               \
-        if (a_tap[H] < p.ntaps) PH_SET_TAP(H);                                                    \
-      }                                                                                           \
-    }                                                                                             \
+    if (live_) PH_ADVANCE(H);                                                                     \
   } while (0)
 
-// stage K tile KT of weight half H into buffer BUFI
-#define PH_STAGE_B(H, BUFI, KT)                                                                   \
+// stage the next K tile of weight half H into buffer BUFI
+#define PH_STAGE_B(H, BUFI)                                                                       \
   do {                                                                                            \
     char* dst_ = smem + (BUFI) * BUF_BYTES + OP_BYTES + (H) * HALF_BYTES + wave * 1024;           \
-    const int kt_ = (KT);                                                                         \
-    const bool live_ = kt_ < nk;                                                                  \
-    const long long woff_ = (long long)kt_ * BK;                                                  \
+    const bool live_ = c_kt[2 + (H)] < nk;                                                        \
+    const long long woff_ = (long long)(c_tap[2 + (H)] * p.nkc + c_cc[2 + (H)]) * BK;             \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                            \
       const int j_ = 2 * (H) + i_;                                                                \
       const u16* src_ = (live_ && w_rv[j_]) ? w_rp[j_] + woff_ : zp;                              \
       __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(dst_ + i_ * 8192), 16, 0, 0);       \
     }                                                                                             \
+    if (live_) PH_ADVANCE(2 + (H));                                                               \
   } while (0)
 
   f32x16 acc[2][2][2];  // [mh][nh][i]
@@ -233,14 +244,12 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
       acc[MH][NH][i_] = T::mfma32(BF[ks_], af[i_][ks_], acc[MH][NH][i_])  /* D[n][m] */
 
   // ---- prologue: K tile 0 complete + the lo halves of K tile 1 (issue order matters for the counted waits) ----
-  PH_SET_TAP(0);
-  PH_SET_TAP(1);
   PH_STAGE_A(0, 0);
-  PH_STAGE_B(0, 0, 0);
-  PH_STAGE_B(1, 0, 0);
+  PH_STAGE_B(0, 0);
+  PH_STAGE_B(1, 0);
   PH_STAGE_A(1, 0);
   PH_STAGE_A(0, 1);
-  PH_STAGE_B(0, 1, 1);
+  PH_STAGE_B(0, 1);
   PH_WAIT_VM8();  // A-lo(0), B-lo(0) of this wave landed
   PH_BARRIER();
   if (grp == 1) PH_BARRIER();  // group 1 runs one barrier behind group 0
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
     // ---- q0 ----
     PH_READ_B(bl, 0, base);
     PH_READ_A(0, base);
-    PH_STAGE_B(1, b ^ 1, t + 1);
+    PH_STAGE_B(1, b ^ 1);
     PH_WAIT_VM8();  // B-hi(t)
     PH_ENTER_MMA();
     PH_MMA(0, 0, bl);
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
     PH_MMA(1, 1, bh);
     PH_LEAVE_MMA();
     // ---- q3 ----
-    PH_STAGE_B(0, b, t + 2);
+    PH_STAGE_B(0, b);
     PH_WAIT_VM8();  // A-lo(t+1), B-lo(t+1)
     PH_ENTER_MMA();
     PH_MMA(1, 0, bl);
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
   if (grp == 0) PH_BARRIER();  // pair group 1's extra barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // zero-page tail loads must land before LDS is reused
   __syncthreads();
-#undef PH_SET_TAP
+#undef PH_ADVANCE
 #undef PH_STAGE_A
 #undef PH_STAGE_B
 #undef PH_READ_A
@@ -442,5 +451,7 @@ int dbir_gemm_ph(const dbir_gemm_desc& dd, int Hv, int Wv, hipStream_t s) {
   }
   p.vec_bias = dd.bias && (reinterpret_cast<uintptr_t>(dd.bias) & 15) == 0;
   p.vec_rv = dd.rowvec && (reinterpret_cast<uintptr_t>(dd.rowvec) & 7) == 0 && dd.rowvec_ld % 4 == 0;
+  static const int tap_inner = getenv("DBIR_TAP_INNER") ? atoi(getenv("DBIR_TAP_INNER")) : 1;  // as gemm_glds.hip
+  p.tap_inner = tap_inner;
   return dd.dtype == DBIR_F16 ? launch_ph<F16>(p, s) : launch_ph<BF16>(p, s);
 }
