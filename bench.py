@@ -122,7 +122,8 @@ def measure_roofline(cldm, device, batch):
     if os.path.exists(pmc):
         with open(pmc) as f:
             t = json.load(f)
-        out["traffic"] = t.get("gemm_bytes_per_launch")
+        if t.get("gemm_bytes_per_eval"):
+            out["traffic"] = t["gemm_bytes_per_eval"] / g[2]   # HBM bytes per logical GEMM launch (incl. split-K slabs)
         out["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     if "attention" in tot:
         a = tot["attention"]

@@ -59,7 +59,12 @@ def main():
         res["families"][fa] = dict(launches=v["launches"], fetch_bytes_per_launch_corrected=2.0 * v["fetch_kib"] * 1024 / n,
                                    write_bytes_per_launch=v["write_kib"] * 1024 / n,
                                    bytes_per_launch=(2.0 * v["fetch_kib"] + v["write_kib"]) * 1024 / n)
-    res["gemm_bytes_per_launch"] = res["families"].get("gemm", {}).get("bytes_per_launch")
+    g = res["families"].get("gemm", {})
+    res["evaluations_profiled"] = 2   # tools/profile_eval.py --pmc-mode: one warm-up + one evaluation
+    res["gemm_bytes_per_kernel_launch"] = g.get("bytes_per_launch")
+    # per LOGICAL GEMM launch of bench.py's roofline record (a split-K GEMM = main kernel + reduce kernel):
+    res["gemm_bytes_per_eval"] = g.get("bytes_per_launch", 0.0) * g.get("launches", 0) / 2.0
+    res["gemm_bytes_per_launch"] = None  # filled by bench.py: gemm_bytes_per_eval / logical launches per evaluation
     with open(dst, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res["families"], indent=1))
