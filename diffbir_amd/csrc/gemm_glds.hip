@@ -76,7 +76,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 // register sets), so the ds_read latency of all but a K tile's first k-step hides under the matrix pipe; with
 // PIPE = 0 the compiler emits read -> s_waitcnt lgkmcnt(0) -> MFMA per k-step and the two waves of a SIMD, which run
 // in lockstep, expose that latency together (rocprofv3: 35 % MFMA utilisation, 43 % of wave cycles in s_waitcnt).
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE>
+// DEPH = 1 (needs STAGES = 3, PIPE = 1): the block's waves form two groups that run HALF A K TILE apart — while group 0
+// issues its share of the next tile's direct-to-LDS loads (a burst paced by the vector memory pipe: ~1000 cycles per
+// K tile when all 8 waves issue at once, measured with s_memtime, during which no MFMA can issue because a wave
+// issues in order), group 1 multiplies, and vice versa; two workgroup barriers per K tile.  Interval I_2k: group 0
+// stages tile k+1 / group 1 multiplies tile k-1; I_2k+1: group 0 multiplies tile k / group 1 stages tile k+1.
+//   RAW: group 0 waits vmcnt(LOADS) after its staging (its share of tile k landed), group 1 waits vmcnt(0) after its
+//        multiply (its share of tile k, issued one interval earlier), both before the barrier that precedes the first
+//        read of tile k;  WAR: tile k+1 refills the slot of tile k-2, last read by group 1 two intervals earlier.
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE, int DEPH>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2Params p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   constexpr int LOADS = RA + RB;
   // BN = 160 (NJ = 5) is not a multiple of the pass height: the weight region is rounded up to whole passes and the
   // rows past BN are fed from the zero page
-  constexpr int A_BYTES = BM * 128, B_BYTES = RB * RPP * 128, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr bool EXACT_B = DEPH && (BN % RPP != 0);  // DEPH needs 3 slots: no room for the round-up rows
+  constexpr int A_BYTES = BM * 128, B_BYTES = (EXACT_B ? BN : RB * RPP) * 128, BUF_BYTES = A_BYTES + B_BYTES;
   static_assert(BM % RPP == 0, "activation tile rows must be a multiple of the pass height");
   static_assert(STAGES >= 2 && (STAGES - 1) * LOADS < 64, "vmcnt is 6 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     const long long woff_ = (long long)(s_tap * p.nkc + s_cc) * BK;                                 \
     _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                \
       const u16* src_ = (w_rv[i] && p.debug != 3) ? w_rp[i] + woff_ : zp;                           \
-      __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(bb_ + i * PASS_BYTES), 16, 0, 0);     \
+      if (!EXACT_B || srow + RPP * i < BN) /* lanes past the tile must not write LDS */             \
+        __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(bb_ + i * PASS_BYTES), 16, 0, 0);   \
     }                                                                                               \
     ++s_kt;                                                                                         \
     s_slot = (s_slot + 1 == STAGES) ? 0 : s_slot + 1;                                               \
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
 
   const int nk = (p.nkc * p.ntaps - kt0 < p.kt_per) ? p.nkc * p.ntaps - kt0 : p.kt_per;
 #pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
+  for (int s = 0; s < (DEPH ? 1 : STAGES - 1); ++s)
     if (s < nk) STAGE();
 
   // fragment read offsets (bytes) inside a stage: row * 128 + ((2*ks + hi) ^ key(row)) * 16
@@ -234,6 +244,53 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   const int sw = (lq >> 1) & 7;
 
   int c_slot = 0;
+  if constexpr (DEPH) {
+    static_assert(STAGES == 3 && PIPE == 1 && (WM * WN) % 2 == 0, "DEPH needs a 3-slot ring and two wave groups");
+    const int grp = wave >= (WM * WN) / 2 ? 1 : 0;
+    wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one interval behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (more) STAGE();
+      if (grp == 0) {
+        if (more)
+          wait_vmcnt<LOADS>();
+        else
+          wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      const char* base = smem + c_slot * BUF_BYTES;
+      c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
+      {
+        typename T::vec8 xf[2][MI], wf[2][NJ];
+#define LOAD_FRAGS_D(KS, SET)                                                                                 \
+  do {                                                                                                        \
+    const int co_ = ((2 * (KS) + hi) ^ sw) * 16;                                                              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) wf[SET][j] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * 4096 + co_);                           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) xf[SET][i] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co_);                           \
+  } while (0)
+        LOAD_FRAGS_D(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks < 3) LOAD_FRAGS_D(ks + 1, (ks + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[ks & 1][j], xf[ks & 1][i], acc[i][j]);
+        }
+#undef LOAD_FRAGS_D
+      }
+      if (grp == 1) wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");  // pairs group 1's extra barrier
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed (this wave's share); later tiles may stay in flight
     if (kt + STAGES - 2 < nk)
@@ -520,17 +577,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
   }
 }
 
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0>
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0>
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-  constexpr int RPP_ = 8 * WM * WN, BNR = (BN + RPP_ - 1) / RPP_ * RPP_;
+  constexpr int RPP_ = 8 * WM * WN, BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
   constexpr int ring = STAGES * (BM + BNR) * 128, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
   constexpr int lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   constexpr int blocks_per_cu = (160 * 1024) / lds;
   constexpr int waves = WM * WN * (blocks_per_cu > 2 ? 2 : blocks_per_cu);
   constexpr int MINW = waves >= 8 ? 2 : 1;
-  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE>;
+  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE, DEPH>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -572,6 +629,10 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
     case 32: return launch2<T, 4, 2, 2, 2, 2, 1>(p, s);
     case 34: return launch2<T, 8, 1, 1, 5, 2, 1>(p, s);
     case 35: return launch2<T, 4, 1, 1, 5, 2, 1>(p, s);
+    // de-phased two-group variants (3-slot ring): staging bursts of one group overlap the MFMAs of the other
+    case 36: return launch2<T, 4, 2, 2, 2, 3, 1, 1>(p, s);  // 256x128
+    case 37: return launch2<T, 8, 1, 1, 5, 3, 1, 1>(p, s);  // 256x160
+    case 38: return launch2<T, 4, 2, 2, 1, 3, 1, 1>(p, s);  // 256x64
   }
   dbir_set_error("dbir_gemm: bad glds tile %d", tile);
   return DBIR_ERR_ARG;
@@ -659,7 +720,7 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
     else
       tile = 5;
   }
-  if (dd.act == DBIR_ACT_GEGLU && (tile == 14 || tile == 15 || tile == 16 || tile == 34 || tile == 35)) {
+  if (dd.act == DBIR_ACT_GEGLU && (tile == 14 || tile == 15 || tile == 16 || tile == 34 || tile == 35 || tile == 37 || tile == 38)) {
     dbir_set_error("dbir_gemm: GEGLU needs a tile whose waves hold value/gate column pairs (tiles 5-13)");
     return DBIR_ERR_ARG;
   }

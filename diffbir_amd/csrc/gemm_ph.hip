@@ -51,6 +51,7 @@ struct PhParams {
   int mtiles, ntiles;
   int vec_bias, vec_rv;
   int tap_inner;
+  int debug;  // DIAGNOSTIC (env DBIR_GEMM_DEBUG=5): per-wave s_memtime phase accumulators into d.ws
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -72,11 +73,21 @@ __device__ __forceinline__ float gelu_fast_ph(float x) {  // same polynomial erf
 #define PH_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define PH_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 // end of a phase's load part -> multiply part
+#define PH_TS(ACC)                                                \
+  do {                                                            \
+    if (instr) {                                                  \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      ACC += now_ - tprev;                                        \
+      tprev = now_;                                               \
+    }                                                             \
+  } while (0)
 #define PH_ENTER_MMA()                               \
   do {                                               \
     __builtin_amdgcn_sched_barrier(0);               \
+    PH_TS(tacc0);                                    \
     PH_BARRIER();                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    PH_TS(tacc1);                                    \
     __builtin_amdgcn_sched_barrier(0);               \
     __builtin_amdgcn_s_setprio(1);                   \
   } while (0)
@@ -84,7 +95,9 @@ __device__ __forceinline__ float gelu_fast_ph(float x) {  // same polynomial erf
   do {                                 \
     __builtin_amdgcn_s_setprio(0);     \
     __builtin_amdgcn_sched_barrier(0); \
+    PH_TS(tacc2);                      \
     PH_BARRIER();                      \
+    PH_TS(tacc3);                      \
     __builtin_amdgcn_sched_barrier(0); \
   } while (0)
 
@@ -254,6 +267,10 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
   PH_BARRIER();
   if (grp == 1) PH_BARRIER();  // group 1 runs one barrier behind group 0
 
+  unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tprev = 0;
+  const bool instr = p.debug == 5;
+  if (instr) tprev = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = tprev;
   for (int t = 0; t < nk; ++t) {
     const int b = t & 1;
     const char* base = smem + b * BUF_BYTES;
@@ -284,6 +301,11 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
     PH_ENTER_MMA();
     PH_MMA(1, 0, bl);
     PH_LEAVE_MMA();
+  }
+  if (instr && d.ws && lane == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(d.ws) + ((long long)blockIdx.x * 8 + wave) * 8;
+    o[0] = tacc0; o[1] = tacc1; o[2] = tacc2; o[3] = tacc3;
+    o[4] = __builtin_amdgcn_s_memtime() - tstart; o[5] = nk;
   }
   if (grp == 0) PH_BARRIER();  // pair group 1's extra barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // zero-page tail loads must land before LDS is reused
@@ -453,5 +475,7 @@ int dbir_gemm_ph(const dbir_gemm_desc& dd, int Hv, int Wv, hipStream_t s) {
   p.vec_rv = dd.rowvec && (reinterpret_cast<uintptr_t>(dd.rowvec) & 7) == 0 && dd.rowvec_ld % 4 == 0;
   static const int tap_inner = getenv("DBIR_TAP_INNER") ? atoi(getenv("DBIR_TAP_INNER")) : 1;  // as gemm_glds.hip
   p.tap_inner = tap_inner;
+  static const int dbg = getenv("DBIR_GEMM_DEBUG") ? atoi(getenv("DBIR_GEMM_DEBUG")) : 0;
+  p.debug = dbg;
   return dd.dtype == DBIR_F16 ? launch_ph<F16>(p, s) : launch_ph<BF16>(p, s);
 }

@@ -90,7 +90,9 @@ typedef struct dbir_gemm_desc {
                6: 256x64, 7: 64x256, 8/9: 256x128 (4 / 8 waves, 3-stage ring), 10: 256x256, 11: 128x128 4-stage,
                12: 256x128 2-stage; 13: phased two-group 256x256 (gemm_ph.hip); 14: 256x160 (8 waves), 15: 128x160,
                16: 256x160 (4 waves) — 160-wide tiles fit the UNet's N = 320 k channel counts without padding;
-               20 + t for t in {5, 6, 10, 12, 14, 15}: tile t with software-pipelined LDS fragment reads */
+               20 + t for t in {5, 6, 10, 12, 14, 15}: tile t with software-pipelined LDS fragment reads;
+               36 / 37 / 38: de-phased two-group 256x128 / 256x160 / 256x64 (3-slot ring, staging of one wave group
+               overlaps the MFMAs of the other) */
   /* split-K (tiles 5-12 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
    * into f32 partial sums in `ws` (>= splitk * batch * M * N * 4 bytes, 16-byte aligned, caller-owned), then a second
    * kernel sums the slices in a fixed order and applies the epilogue.  For small-M / huge-K problems (8x8 and 16x16

@@ -187,8 +187,9 @@ def test_conv3x3_fused_epilogue(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
-GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 25, 26, 30, 32, 34, 35]   # 20 + t: pipelined fragment reads
-NO_GEGLU_TILES = (14, 15, 16, 34, 35)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
+GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38]
+# 20 + t: tile t with pipelined fragment reads; 36-38: de-phased two-group variants
+NO_GEGLU_TILES = (14, 15, 16, 34, 35, 37, 38)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -349,8 +350,9 @@ def test_glds_splitk(code, dtype):
         ops.linear(xl, pl, tile=13 + 100 * 2)   # the phased kernel has no split-K
 
 
+@pytest.mark.parametrize("tile13", [13, 36, 37, 38])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_phased_gemm_race_screen(dtype):
+def test_phased_gemm_race_screen(dtype, tile13):
     """Tile 13 (two staggered wave groups, counted vmcnt across barriers) at full-chip sizes, repeated, against the
     2-stage 128x128 kernel (tile 5).  Both kernels feed every output element the same MFMA sequence (K tiles in order,
     16 k per instruction), so the results must be BIT-identical: any LDS read-before-land / restage-before-read race
@@ -371,7 +373,8 @@ def test_phased_gemm_race_screen(dtype):
     x4 = rnd(65536, 320, dtype=dtype, seed=9)
     pw4 = ops.pack_geglu(rnd(2560, 320, dtype=torch.float32, s=0.05, seed=10).cpu(),
                          rnd(2560, dtype=torch.float32, seed=11).cpu(), dtype, DEV)
-    cases.append(("geglu 65536x1280x320", lambda t: ops.linear(x4, pw4, tile=t)))
+    if tile13 not in NO_GEGLU_TILES:
+        cases.append(("geglu 65536x1280x320", lambda t: ops.linear(x4, pw4, tile=t)))
     x5 = rnd(8, 33, 47, 64, dtype=dtype, seed=12)   # ragged M, odd image, single channel tile per tap
     pw5 = ops.pack_conv3x3(rnd(200, 64, 3, 3, dtype=torch.float32, s=0.05, seed=13).cpu(), None, dtype, DEV)
     cases.append(("conv 8x33x47 64->200 s2", lambda t: ops.conv3x3(x5, pw5, stride=2, tile=t)))
@@ -379,11 +382,11 @@ def test_phased_gemm_race_screen(dtype):
     for name, fn in cases:
         ref = fn(5).clone().float()
         for it in range(6):
-            got = fn(13).float()
+            got = fn(tile13).float()
             # identical MFMA sequences -> normally bit-identical; allow 1 ulp for epilogue FMA-contraction differences
             # between the two translation units.  A staging race corrupts whole K tiles: orders of magnitude larger.
             bad = (got - ref).abs() > ulp * ref.abs() + 1e-6
-            assert not bad.any(), f"{name}: tile 13 differs from tile 5 (iteration {it}): " \
+            assert not bad.any(), f"{name}: tile {tile13} differs from tile 5 (iteration {it}): " \
                 f"{(got - ref).abs().max().item():.3e} max abs, {bad.float().mean().item():.2e} of the elements"
 
 

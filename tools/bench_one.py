@@ -33,6 +33,26 @@ def main():
         out = torch.empty(M, N, dtype=DT, device=DEV)
         fn = lambda: ops.linear(x, pw, out=out, tile=tile)
         fl = 2.0 * M * N * K
+    if os.environ.get("DBIR_GEMM_DEBUG") == "5":
+        import ctypes
+        ws = torch.zeros(1 << 22, dtype=torch.int64, device=DEV)
+        orig = ops.apply_tile_code
+
+        def patched(d, code, device):
+            orig(d, code, device)
+            d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
+        ops.apply_tile_code = patched
+        fn()
+        torch.cuda.synchronize()
+        v = ws.reshape(-1, 8)
+        v = v[v[:, 5] > 0].double()
+        nk = v[:, 5].mean().item()
+        names = (["load part (reads+glds+vmcnt)", "barrier1+lgkmcnt", "MFMA issue", "barrier2", "loop total"] if tile == 13 else
+                 ["vmcnt wait", "barrier wait", "stage issue", "reads+MFMA issue", "loop total"])
+        print(f"instrumented waves: {v.shape[0]}, K tiles per block {nk:.0f}; cycles per K tile (s_memtime ticks):")
+        for i, n in enumerate(names):
+            print(f"   {n:30s} mean {v[:, i].mean().item() / nk:8.0f}   min {v[:, i].min().item() / nk:8.0f}   max {v[:, i].max().item() / nk:8.0f}")
+        return
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
