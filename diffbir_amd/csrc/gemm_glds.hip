@@ -45,6 +45,7 @@ struct G2Params {
   int vec_bias, vec_rv;  // bias / row vector may be read with 16 B / 8 B vector loads
   int splitk, kt_per;    // split-K: number of K slices (1 = off) and K tiles per slice
   float* ws;             // split-K: f32 partial sums [z][slice][M][N]
+  long long a_elems;     // elements of the activation tensor addressable from d.A (+ batch z offset)
   int tap_inner;         // conv K order: 1 = (channel tile, tap), 0 = (tap, channel tile)
   int debug;             // DIAGNOSTIC (env DBIR_GEMM_DEBUG): 1 = skip steady-state staging, 2 = skip MFMAs
 };
@@ -122,18 +123,52 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   const int M = d.M;
   const u16* __restrict__ Ag = reinterpret_cast<const u16*>(d.A) + (long long)bz * d.strideA_z;
   const u16* __restrict__ Wg = reinterpret_cast<const u16*>(d.W) + (long long)bz * d.strideW_z;
-  const u16* zp = reinterpret_cast<const u16*>(g_zero_page);
 
   // ---- staging roles: thread handles LDS chunk position (row = (tid>>3) + RPP*i, cpos = tid&7) ----
   const int srow = tid >> 3;
   const int cch = ((tid & 7) ^ ((srow >> 1) & 7)) * 8;  // logical K offset (halfs) of the chunk this thread fetches
   const bool conv = d.mode == DBIR_MODE_CONV3X3;
 
-  // Activation rows: pointer to the element of tap (0,0) (never dereferenced when that tap is outside the image) and
-  // a 9-bit tap validity mask; for a nearest-x2 upsampled input bits 16/17 hold the x/y parity that decides whether
-  // tap k moves to the next source pixel ((k + parity) >> 1).  The per-K-tile source address is then
-  // a_base[i] + <scalar offset of (tap, channel tile)>: no per-tap re-derivation of coordinates.
-  const u16* a_base[RA];
+  // Operands are fetched with `buffer_load_dwordx4 ... lds` through two block-local buffer descriptors (SRD): the
+  // per-lane part of an address is a 32-bit byte offset from a block-uniform base (the lowest address the tile can
+  // touch), the (tap, channel-tile) part of a K tile goes into the scalar offset operand, and padding / out-of-tile
+  // rows use an out-of-range offset for which the hardware returns zeros — no zero page, no 64-bit per-lane pointer
+  // math, no select per load (the staging burst was ~1000 of ~2850 cycles per K tile with flat global loads).
+  constexpr int OOB = 0x7fffff00;  // >= num_records of every descriptor below
+  long long a_ref;                 // element offset (from Ag) of the block's lowest activation address
+  {
+    const int m0 = tm * BM < M ? tm * BM : M - 1;
+    if (conv) {
+      const int hw = d.Ho * d.Wo;
+      const int b0 = m0 / hw, rem0 = m0 - b0 * hw;
+      const int oy0 = rem0 / d.Wo, ox0 = rem0 - oy0 * d.Wo;
+      int sy0 = oy0 * d.stride - d.pad, sx0 = ox0 * d.stride - d.pad;
+      if (d.upsample) {
+        sy0 >>= 1;
+        sx0 >>= 1;
+      }
+      // rows of a tile have non-decreasing (b, oy, ox), hence non-decreasing tap-(0,0) addresses; one pixel of slack
+      a_ref = ((long long)b0 * d.Hi * d.Wi + (long long)sy0 * d.Wi + sx0 - 1) * d.Cin;
+    } else {
+      a_ref = (long long)m0 * d.lda;
+    }
+  }
+  long long a_left = (p.a_elems - a_ref) * 2;  // bytes from the descriptor base to the end of the activation tensor
+  if (a_left > 0x7ffffe00LL) a_left = 0x7ffffe00LL;
+  if (a_left < 0) a_left = 0;
+  const __amdgpu_buffer_rsrc_t a_srd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(Ag) + a_ref, 0, (int)a_left, 0x00020000);
+  const long long w_ref = (long long)tn * BN * d.Kpad;
+  long long w_left = ((long long)d.Wrows * d.Kpad - w_ref) * 2;
+  if (w_left > 0x7ffffe00LL) w_left = 0x7ffffe00LL;
+  if (w_left < 0) w_left = 0;
+  const __amdgpu_buffer_rsrc_t w_srd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(Wg) + w_ref, 0, (int)w_left, 0x00020000);
+
+  // Activation rows: byte offset (from the descriptor base) of the element of tap (0,0) and a 9-bit tap validity
+  // mask; for a nearest-x2 upsampled input bits 16/17 hold the x/y parity that decides whether tap k moves to the
+  // next source pixel ((k + parity) >> 1).
+  int a_voff[RA];
   unsigned a_mask[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
@@ -159,19 +194,19 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
         sx >>= 1;
       }
       a_mask[i] = mk;
-      a_base[i] = Ag + ((long long)b * d.Hi * d.Wi + (long long)sy * d.Wi + sx) * d.Cin + cch;
+      const long long e = ((long long)b * d.Hi * d.Wi + (long long)sy * d.Wi + sx) * d.Cin + cch - a_ref;
+      a_voff[i] = (int)(e * 2);
     } else {
       a_mask[i] = ok ? 1u : 0u;
-      a_base[i] = Ag + (long long)(ok ? m : 0) * d.lda + cch;
+      a_voff[i] = (int)(((long long)(ok ? m : 0) * d.lda + cch - a_ref) * 2);
     }
   }
-  const u16* w_rp[RB];
-  bool w_rv[RB];
+  int w_voff[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int n = tn * BN + srow + RPP * i;
-    w_rv[i] = n < d.Wrows && srow + RPP * i < BN;
-    w_rp[i] = w_rv[i] ? Wg + (long long)n * d.Kpad + cch : zp;
+    const int nl = srow + RPP * i;
+    const bool ok = tn * BN + nl < d.Wrows && nl < BN;
+    w_voff[i] = ok ? (int)(((long long)nl * d.Kpad + cch) * 2) : OOB;
   }
 
   // staging cursor (uniform): K tile, tap, channel tile, ring slot.  K tiles are visited TAP-INNER for convolutions
@@ -194,23 +229,29 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     char* ab_ = smem + s_slot * BUF_BYTES + wave * 1024;                                            \
     char* bb_ = ab_ + A_BYTES;                                                                      \
     const int ky_ = (s_tap * 11) >> 5, kx_ = s_tap - 3 * ky_;                                       \
-    const long long aoff_ = (long long)(ky_ * d.Wi + kx_) * d.Cin + s_cc * BK;                      \
-    _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                                \
-      long long o_ = aoff_;                                                                         \
-      if (d.upsample) {                                                                             \
+    const int koff_ = s_cc * (BK * 2);                          /* bytes, scalar operand */         \
+    const unsigned tbit_ = 1u << s_tap;                                                             \
+    if (!d.upsample) {                                                                              \
+      const int toff_ = (ky_ * d.Wi + kx_) * d.Cin * 2;         /* bytes, uniform */                \
+      _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                              \
+        const int v_ = (a_mask[i] & tbit_) ? a_voff[i] + toff_ : OOB;                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_srd, (lptr_t)(ab_ + i * PASS_BYTES), 16, v_,     \
+                                                 koff_, 0, 0);                                      \
+      }                                                                                             \
+    } else {                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                              \
         const int dy_ = (ky_ + (int)((a_mask[i] >> 17) & 1)) >> 1;                                  \
         const int dx_ = (kx_ + (int)((a_mask[i] >> 16) & 1)) >> 1;                                  \
-        o_ = (long long)(dy_ * d.Wi + dx_) * d.Cin + s_cc * BK;                                     \
+        const int v_ = (a_mask[i] & tbit_) ? a_voff[i] + (dy_ * d.Wi + dx_) * d.Cin * 2 : OOB;      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_srd, (lptr_t)(ab_ + i * PASS_BYTES), 16, v_,     \
+                                                 koff_, 0, 0);                                      \
       }                                                                                             \
-      const bool v_ = ((a_mask[i] >> s_tap) & 1u) && p.debug != 3;                                  \
-      const u16* src_ = v_ ? a_base[i] + o_ : zp;                                                   \
-      __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(ab_ + i * PASS_BYTES), 16, 0, 0);     \
     }                                                                                               \
-    const long long woff_ = (long long)(s_tap * p.nkc + s_cc) * BK;                                 \
+    const int woff_ = (s_tap * p.nkc + s_cc) * (BK * 2);                                            \
     _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                \
-      const u16* src_ = (w_rv[i] && p.debug != 3) ? w_rp[i] + woff_ : zp;                           \
       if (!EXACT_B || srow + RPP * i < BN) /* lanes past the tile must not write LDS */             \
-        __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(bb_ + i * PASS_BYTES), 16, 0, 0);   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_srd, (lptr_t)(bb_ + i * PASS_BYTES), 16,         \
+                                                 w_voff[i], woff_, 0, 0);                           \
     }                                                                                               \
     ++s_kt;                                                                                         \
     s_slot = (s_slot + 1 == STAGES) ? 0 : s_slot + 1;                                               \
@@ -250,6 +291,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     wait_vmcnt<0>();
     asm volatile("s_barrier" ::: "memory");
     if (grp == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one interval behind group 0
+    unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tprev = 0;
+    const bool instr = p.debug == 5;
+#define TSD(ACC)                                                   \
+  do {                                                             \
+    if (instr) {                                                   \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      ACC += now_ - tprev;                                         \
+      tprev = now_;                                                \
+    }                                                              \
+  } while (0)
+    if (instr) tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = kt + 1 < nk;
       if (more) STAGE();
@@ -259,8 +312,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
         else
           wait_vmcnt<0>();
       }
+      TSD(tacc0);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
+      TSD(tacc1);
       const char* base = smem + c_slot * BUF_BYTES;
       c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
       {
@@ -286,9 +341,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
 #undef LOAD_FRAGS_D
       }
       if (grp == 1) wait_vmcnt<0>();
+      TSD(tacc2);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
+      TSD(tacc3);
     }
+    if (instr && p.ws && lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + ((long long)blockIdx.x * (WM * WN) + wave) * 8;
+      o[0] = tacc0; o[1] = tacc1; o[2] = tacc2; o[3] = tacc3;
+      o[4] = __builtin_amdgcn_s_memtime() - tstart; o[5] = nk; o[6] = grp;
+    }
+#undef TSD
     if (grp == 0) asm volatile("s_barrier" ::: "memory");  // pairs group 1's extra barrier
   } else
   for (int kt = 0; kt < nk; ++kt) {
@@ -683,6 +746,8 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
     static const int tap_inner = getenv("DBIR_TAP_INNER") ? atoi(getenv("DBIR_TAP_INNER")) : 1;  // A/B switch
     p.debug = dbg;
     p.tap_inner = tap_inner;
+    p.a_elems = dd.mode == DBIR_MODE_CONV3X3 ? (long long)dd.B * dd.Hi * dd.Wi * dd.Cin
+                                             : (long long)(dd.M - 1) * dd.lda + dd.K;
   }
   {
     // split-K (explicit request only): slices of whole K tiles; every slice must be non-empty
@@ -692,6 +757,7 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
     p.kt_per = cdiv(nk_total, sk);
     p.splitk = cdiv(nk_total, p.kt_per);
     p.ws = reinterpret_cast<float*>(dd.ws);
+    if (p.debug == 5 && p.splitk > 1) p.debug = 0;  // the diagnostic timestamps share the workspace pointer
     if (p.splitk > 1) {
       const long long need = (long long)p.splitk * (dd.batch > 0 ? dd.batch : 1) * dd.M * dd.N * 4;
       if (!dd.ws || dd.ws_bytes < need || (reinterpret_cast<uintptr_t>(dd.ws) & 15)) {

@@ -47,6 +47,13 @@ def main():
         v = ws.reshape(-1, 8)
         v = v[v[:, 5] > 0].double()
         nk = v[:, 5].mean().item()
+        if tile in (36, 37, 38):
+            for g in (0, 1):
+                vg = v[v[:, 6] == g]
+                print(f" group {g}: stage(+vmcnt) {vg[:,0].mean().item()/nk:.0f}  barrier1 {vg[:,1].mean().item()/nk:.0f}  "
+                      f"reads+MFMA(+vmcnt0 for g1) {vg[:,2].mean().item()/nk:.0f}  barrier2 {vg[:,3].mean().item()/nk:.0f}  "
+                      f"total {vg[:,4].mean().item()/nk:.0f} cycles per K tile")
+            return
         names = (["load part (reads+glds+vmcnt)", "barrier1+lgkmcnt", "MFMA issue", "barrier2", "loop total"] if tile == 13 else
                  ["vmcnt wait", "barrier wait", "stage issue", "reads+MFMA issue", "loop total"])
         print(f"instrumented waves: {v.shape[0]}, K tiles per block {nk:.0f}; cycles per K tile (s_memtime ticks):")
