@@ -87,6 +87,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //        read of tile k;  WAR: tile k+1 refills the slot of tile k-2, last read by group 1 two intervals earlier.
 template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE, int DEPH>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the body uses gfx950-only builtins (buffer descriptors, LDS-DMA, MFMA)
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int RPP = NT / 8;                  // tile rows covered by one glds pass of the whole block
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       }
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // Split-K second pass: sum the K slices in a fixed order (deterministic), then the same epilogue as the fused path
