@@ -148,8 +148,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
         sy0 >>= 1;
         sx0 >>= 1;
       }
-      // rows of a tile have non-decreasing (b, oy, ox), hence non-decreasing tap-(0,0) addresses; one pixel of slack
-      a_ref = ((long long)b0 * d.Hi * d.Wi + (long long)sy0 * d.Wi + sx0 - 1) * d.Cin;
+      // rows of a tile have non-decreasing (b, oy): reference = start of the first row's source line (sx >= -1);
+      // with the nearest-x2 upsample two output lines share a source line, so the column must not enter the bound
+      (void)sx0;
+      a_ref = ((long long)b0 * d.Hi * d.Wi + (long long)sy0 * d.Wi - 2) * d.Cin;
     } else {
       a_ref = (long long)m0 * d.lda;
     }
