@@ -1,9 +1,10 @@
 #!/bin/sh
-# Build libdbir_hip.so (gfx950) in-tree. Usage: sh diffbir_amd/csrc/build.sh
+# Build libdbir_hip.so (gfx950) in-tree. Usage: sh diffbir_amd/csrc/build.sh   (DBIR_DIAG=1 adds the GEMM diagnostics)
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+if [ -n "$DBIR_DIAG" ]; then FLAGS="$FLAGS -DDBIR_DIAG"; rm -f build/gemm_glds.o build/gemm_ph.o; fi
 mkdir -p build
 for f in api gemm gemm_glds gemm_ph attention norm elementwise swin; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/dbir.h -nt build/$f.o ]; then

@@ -33,6 +33,12 @@
 namespace {
 
 constexpr int BK = 64;
+#ifdef DBIR_DIAG  // diagnostic build (sh build.sh -DDBIR_DIAG): env DBIR_GEMM_DEBUG = 1 skip staging, 2 skip MFMAs,
+                  // 5 s_memtime interval accumulators (de-phased kernels) into the workspace pointer
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];  // zero-initialised device memory
 
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     asm volatile("s_barrier" ::: "memory");
     if (grp == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one interval behind group 0
     unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tprev = 0;
-    const bool instr = p.debug == 5;
+    const bool instr = kDiag && p.debug == 5;
 #define TSD(ACC)                                                   \
   do {                                                             \
     if (instr) {                                                   \
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     const char* base = smem + c_slot * BUF_BYTES;
     c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
     if constexpr (!PIPE) {
-      if (kt + STAGES - 1 < nk && p.debug != 1) STAGE();
+      if (kt + STAGES - 1 < nk && (!kDiag || p.debug != 1)) STAGE();
     }
     if constexpr (PIPE) {
       typename T::vec8 xf[2][MI], wf[2][NJ];
@@ -384,8 +390,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       __builtin_amdgcn_sched_barrier(0);
       // the next tile's direct-to-LDS loads are issued while the first fragment reads are in flight (the slot they
       // refill was last read before the barrier above)
-      if (kt + STAGES - 1 < nk && p.debug != 1) STAGE();
-      if (p.debug == 2) continue;
+      if (kt + STAGES - 1 < nk && (!kDiag || p.debug != 1)) STAGE();
+      if (kDiag && p.debug == 2) continue;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks < 3) LOAD_FRAGS(ks + 1, (ks + 1) & 1);
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       }
 #undef LOAD_FRAGS
     } else {
-      if (p.debug == 2) continue;
+      if (kDiag && p.debug == 2) continue;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int co = ((2 * ks + hi) ^ sw) * 16;

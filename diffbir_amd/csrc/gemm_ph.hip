@@ -35,6 +35,11 @@
 namespace {
 
 constexpr int BK = 64;
+#ifdef DBIR_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
 constexpr int PBM = 256, PBN = 256, PNT = 512;
 constexpr int HALF_BYTES = 128 * 128;        // 128 rows x 128 B
 constexpr int OP_BYTES = 2 * HALF_BYTES;     // one operand of one K tile
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(PNT) void gemm_ph_kernel(const PhParams p) {
   if (grp == 1) PH_BARRIER();  // group 1 runs one barrier behind group 0
 
   unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tprev = 0;
-  const bool instr = p.debug == 5;
+  const bool instr = kDiag && p.debug == 5;
   if (instr) tprev = __builtin_amdgcn_s_memtime();
   const unsigned long long tstart = tprev;
   for (int t = 0; t < nk; ++t) {
