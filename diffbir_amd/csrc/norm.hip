@@ -212,6 +212,63 @@ __global__ __launch_bounds__(256) void ln_kernel(const u16* __restrict__ x, long
   }
 }
 
+// LayerNorm, lane-group variant: LPR lanes share a row (64 / LPR rows per wave), each lane holds CPL 16-byte chunks
+// (chunk index j + LPR*k), so all 64 lanes load even for narrow rows (C = 320 is 40 chunks: the wave-per-row kernel
+// above leaves 24 of 64 lanes idle there) and every load instruction covers whole 128-byte segments of 64/LPR rows.
+// Two-pass f32 statistics with xor-shuffle reductions inside the lane group.
+template <typename T, int LPR, int CPL>
+__global__ __launch_bounds__(256) void ln2_kernel(const u16* __restrict__ x, long long ldx, u16* __restrict__ y,
+                                                  long long ldy, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int rows, int C, float eps) {
+  constexpr int RPW = 64 / LPR;  // rows per wave
+  const int lane = threadIdx.x & 63;
+  const int j = lane % LPR;
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool rok = row < rows;
+  const long long rr = rok ? row : rows - 1;
+  float f[CPL][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int v = j + LPR * k;
+    const uint4 q = *reinterpret_cast<const uint4*>(x + rr * ldx + v * 8);
+    unpack8<T>(q, f[k]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (v * 8 + e >= C) f[k][e] = 0.f;
+      sum += f[k][e];
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int v = j + LPR * k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dlt = (v * 8 + e < C) ? f[k][e] - mean : 0.f;
+      sq += dlt * dlt;
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  if (!rok) return;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int v = j + LPR * k;
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = v * 8 + e;
+      o8[e] = c < C ? (f[k][e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+    }
+    *reinterpret_cast<uint4*>(y + row * ldy + v * 8) = pack8<T>(o8);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row softmax in place (one 256-thread block per row).
 // ------------------------------------------------------------------------------------------------
@@ -321,6 +378,19 @@ extern "C" int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, 
   DBIR_CHECK_ARG(rows > 0, "dbir_layernorm: bad rows");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nv = Cpad / 8;
+#define LN2_LAUNCH(TT, LPR, CPL)                                                                                   \
+  hipLaunchKernelGGL((ln2_kernel<TT, LPR, CPL>), dim3((unsigned)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))),   \
+                     dim3(256), 0, s, (const u16*)x, ldx, (u16*)y, ldy, gamma, beta, rows, C, eps)
+#define LN2_TRY(TT)                                                                                                \
+  do {                                                                                                             \
+    if (nv == 40) { LN2_LAUNCH(TT, 8, 5); goto ln_done; }   /* C = 320 */                                          \
+    if (nv == 80) { LN2_LAUNCH(TT, 16, 5); goto ln_done; }  /* C = 640 */                                          \
+    if (nv == 160) { LN2_LAUNCH(TT, 32, 5); goto ln_done; } /* C = 1280 */                                         \
+    if (nv == 24) { LN2_LAUNCH(TT, 8, 3); goto ln_done; }   /* SwinIR C = 180 (padded to 192) */                   \
+    if (nv == 8) { LN2_LAUNCH(TT, 8, 1); goto ln_done; }                                                           \
+  } while (0)
+  if (dtype == DBIR_F16) LN2_TRY(F16);
+  else if (dtype == DBIR_BF16) LN2_TRY(BF16);
 #define LN_LAUNCH(TT, MV, RW)                                                                                     \
   hipLaunchKernelGGL((ln_kernel<TT, MV, RW>), dim3((rows + 4 * RW - 1) / (4 * RW)), dim3(256), 0, s, (const u16*)x, \
                      ldx, (u16*)y, ldy, gamma, beta, rows, C, Cpad, eps)
@@ -337,6 +407,9 @@ extern "C" int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, 
     return DBIR_ERR_ARG;
   }
 #undef LN_LAUNCH
+ln_done:
+#undef LN2_TRY
+#undef LN2_LAUNCH
   DBIR_CHECK_LAUNCH("dbir_layernorm");
   return DBIR_OK;
 }
