@@ -259,12 +259,22 @@ __global__ __launch_bounds__(256) void ln2_kernel(const u16* __restrict__ x, lon
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
     const int v = j + LPR * k;
-    float o8[8];
+    float o8[8], gm[8], bt[8];
+    if (v * 8 + 8 <= C) {  // whole chunk inside C: 16-byte loads of the affine parameters (L1-resident)
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + v * 8), g1 = *reinterpret_cast<const float4*>(gamma + v * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + v * 8), b1 = *reinterpret_cast<const float4*>(beta + v * 8 + 4);
+      gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
+      bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = v * 8 + e;
-      o8[e] = c < C ? (f[k][e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const int c = v * 8 + e;
+        gm[e] = c < C ? gamma[c] : 0.f;
+        bt[e] = c < C ? beta[c] : 0.f;
+      }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (v * 8 + e < C) ? (f[k][e] - mean) * rstd * gm[e] + bt[e] : 0.f;
     *reinterpret_cast<uint4*>(y + row * ldy + v * 8) = pack8<T>(o8);
   }
 }
