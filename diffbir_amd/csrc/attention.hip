@@ -189,7 +189,6 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
                                                        const u16* __restrict__ Vt, long long vt_bs, long long ldvt,
                                                        u16* __restrict__ O, long long o_bs, long long ldo, int H,
                                                        int Lq, int Lk, float c /* scale * log2(e) */) {
-#if defined(__HIP_DEVICE_COMPILE__)  // gfx950-only builtins (buffer descriptors)
   constexpr int KS_HALFS = KT * K_LD, VS_HALFS = 64 * V_LD;
   __shared__ __attribute__((aligned(16))) u16 lds[2 * (KS_HALFS + VS_HALFS)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -235,36 +234,19 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
   const int kc = tid & 7, r0 = tid >> 3;
   const int ntiles = (Lk + KT - 1) / KT;
 
-  // K / V^T tiles are fetched through two buffer descriptors (base = this (batch, head)'s slice, per-lane 32-bit
-  // offsets fixed for the whole kernel + one scalar add per tile; keys >= Lk fall outside the K descriptor and read
-  // as zero): the flat-address version spent ~540 of ~1600 cycles per tile issuing its 4 predicated loads.
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  constexpr int OOB = 0x7fffff00;
-  const long long k_bytes = ((long long)(Lk - 1) * ldk + 64) * 2, v_bytes = ((long long)63 * ldvt + ldvt) * 2;
-  const __amdgpu_buffer_rsrc_t k_srd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(Kg), 0, (int)(k_bytes < 0x7ffffe00LL ? k_bytes : 0x7ffffe00LL), 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_srd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(Vg), 0, (int)(v_bytes < 0x7ffffe00LL ? v_bytes : 0x7ffffe00LL), 0x00020000);
-  int k_voff[2], v_voff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    k_voff[i] = (int)(((long long)(r0 + 32 * i) * ldk + kc * 8) * 2);
-    v_voff[i] = (int)(((long long)(r0 + 32 * i) * ldvt + kc * 8) * 2);
-  }
-  const int k_step = (int)((long long)KT * ldk * 2);  // bytes per key tile
   uint4 kreg[2], vreg[2];
   auto fetch = [&](int kt) {  // global -> registers (zero-filled outside [0, Lk))
     const int key0 = kt * KT;
-    const bool ragged = key0 + KT > Lk;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      // keys >= Lk: the offset is past the descriptor's num_records -> zeros
-      const u32x4 kk = __builtin_amdgcn_raw_buffer_load_b128(k_srd, k_voff[i] + kt * k_step, 0, 0);
-      kreg[i] = make_uint4(kk.x, kk.y, kk.z, kk.w);
-      int vo = v_voff[i] + key0 * 2;
-      if (ragged && key0 + kc * 8 >= Lk) vo = OOB;  // whole chunk beyond Lk (partial chunks are masked in commit)
-      const u32x4 vv = __builtin_amdgcn_raw_buffer_load_b128(v_srd, vo, 0, 0);
-      vreg[i] = make_uint4(vv.x, vv.y, vv.z, vv.w);
+      const int row = r0 + 32 * i;
+      const int key = key0 + row;
+      kreg[i] = make_uint4(0, 0, 0, 0);
+      if (key < Lk) kreg[i] = *reinterpret_cast<const uint4*>(Kg + (long long)key * ldk + kc * 8);
+      const int kcol = key0 + kc * 8;
+      uint4 vv = make_uint4(0, 0, 0, 0);
+      if (kcol < Lk) vv = *reinterpret_cast<const uint4*>(Vg + (long long)row * ldvt + kcol);
+      vreg[i] = vv;
     }
   };
   auto commit = [&](int buf, int kt) {  // registers -> LDS buffer (touching the loaded values only here keeps the
@@ -295,24 +277,12 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
   commit(0, 0);
   __syncthreads();
 
-#ifdef DBIR_DIAG
-  unsigned long long ta[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
-#define ATS(I)                                                    \
-  do {                                                            \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-    ta[I] += now_ - tprev;                                        \
-    tprev = now_;                                                 \
-  } while (0)
-#else
-#define ATS(I)
-#endif
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * KT;
     const u16* Ks = lds + (kt & 1) * (KS_HALFS + VS_HALFS);
     const u16* Vs = Ks + KS_HALFS;
     const bool more = kt + 1 < ntiles;
     if (more) fetch(kt + 1);  // in flight during this tile's MFMAs
-    ATS(0);
 
     f32x16 s_acc[2];
 #pragma unroll
@@ -326,8 +296,6 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
         s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
       }
     }
-    asm volatile("" ::"v"(s_acc[1][15]));
-    ATS(1);
     if (key0 + KT > Lk) {  // ragged last tile: mask keys >= Lk (wave-uniform branch)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -366,7 +334,6 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
       }
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
-    ATS(2);
 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -384,27 +351,9 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
         o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
       }
     }
-    ATS(3);
     if (more) commit((kt + 1) & 1, kt + 1);  // the other buffer was last read in iteration kt-1 (barrier since)
-    ATS(4);
     __syncthreads();
-    ATS(5);
   }
-#ifdef DBIR_DIAG
-  if (lane == 0 && blockIdx.x < 4096 && gridDim.x >= 1) {
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(O) ;  // DIAG build only: overwrites the first rows of O
-    (void)o;
-  }
-  if (lane == 0) {
-    // DIAG: accumulators are written to a side buffer passed through the (unused in diag runs) tail of Vt? No: printf-free
-    // export — reuse the output rows of this block (the diag harness does not check O).
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(O + (long long)b * o_bs + (long long)(qb * 128 + wave * 32) * ldo + h * 64);
-    for (int i = 0; i < 6; ++i) o[i] = ta[i];
-    o[6] = ntiles;
-  }
-  return;
-#endif
-#undef ATS
 
   if (q_ok) {
     const float inv = 1.0f / l_run;
@@ -422,7 +371,6 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
         *reinterpret_cast<uint2*>(op + t * 32 + 8 * g + 4 * hi) = pk;
       }
   }
-#endif  // __HIP_DEVICE_COMPILE__
 }
 
 int g_attn_variant = 2;
