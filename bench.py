@@ -96,12 +96,14 @@ def measure_roofline(cldm, device, batch):
     c_txt = torch.randn(2 * batch, 77, 1024, device=device)
     t = torch.full((2 * batch,), 500.0, device=device)
     cond = dict(c_txt=c_txt, c_img=c_img)
+    overlap, cldm.overlap_streams = cldm.overlap_streams, False   # per-launch durations are measured un-overlapped
     cldm(x, t, cond)  # warm (context K/V cache, allocator)
     torch.cuda.synchronize()
     prof = ops.start_profile()
     cldm(x, t, cond)
     torch.cuda.synchronize()
     rec = ops.stop_profile()
+    cldm.overlap_streams = overlap
     tot = {}
     for kind, flops, e0, e1, _tag, nbytes in rec:
         ms = e0.elapsed_time(e1)

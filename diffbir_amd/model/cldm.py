@@ -25,6 +25,11 @@ class ControlLDM:
         self.scale_factor = latent_scale_factor
         self.control_scales = [1.0] * 13
         self._mods = [self.unet, self.vae, self.clip, self.controlnet]
+        # engine option: run the ControlNet on a second HIP stream while the UNet encoder (which does not depend on it,
+        # controlnet.py:30-38) runs on the current one; the streams join before the middle-block control is added.
+        # The two networks have the same shapes, and the 16x16 / 8x8 latent levels alone cannot fill 256 CUs.
+        self.overlap_streams = True
+        self._side_stream = {}
 
     # ---- weights ------------------------------------------------------------------------------
     @torch.no_grad()
@@ -92,8 +97,21 @@ class ControlLDM:
     def forward(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
         """reference cldm.py:160-172. x f32 [B,4,h,w], t [B] (int or fractional), cond {c_txt, c_img} -> f32."""
         c_txt, c_img = cond["c_txt"], cond["c_img"]
-        control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales)
-        return self.unet(x_noisy, t, c_txt, control, only_mid_control=False)
+        if not (self.overlap_streams and x_noisy.is_cuda):
+            control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales)
+            return self.unet(x_noisy, t, c_txt, control, only_mid_control=False)
+        main = torch.cuda.current_stream()
+        side = self._side_stream.get(x_noisy.device)
+        if side is None:
+            side = self._side_stream[x_noisy.device] = torch.cuda.Stream(device=x_noisy.device)
+        side.wait_stream(main)                      # inputs produced on the main stream are ready
+        with torch.cuda.stream(side):
+            control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales)
+            done = torch.cuda.Event()
+            done.record(side)
+        for c in control:                           # allocated on `side`, consumed (and later freed) on `main`
+            c.record_stream(main)
+        return self.unet(x_noisy, t, c_txt, control, only_mid_control=False, control_ready=done)
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)

@@ -226,13 +226,17 @@ class ControlledUnetModel(_DiffusionNet):
         self._finish_emb()
 
     def forward(self, x: T, timesteps: T, context: T, control: Optional[List[T]] = None,
-                only_mid_control: bool = False, **_) -> T:
-        """x: f32 NCHW [B,4,h,w]; control: list of 13 NHWC 16-bit tensors (already scaled) or None -> f32 NCHW."""
+                only_mid_control: bool = False, control_ready=None, **_) -> T:
+        """x: f32 NCHW [B,4,h,w]; control: list of 13 NHWC 16-bit tensors (already scaled) or None -> f32 NCHW.
+        control_ready: optional torch.cuda.Event recorded by the stream that produces `control` (ControlLDM runs the
+        ControlNet concurrently with this encoder); waited for right before the first control tensor is read."""
         self._ensure_packed()
         ctx_kv = self.context_kv(context)
         emb_all = self._time_emb(timesteps)
         h = ops.nchw_to_nhwc(x.float().contiguous(), None, 8, self._dtype)
         hs, h = self._encode(h, emb_all, ctx_kv)
+        if control_ready is not None:
+            torch.cuda.current_stream().wait_event(control_ready)
         control = list(control) if control is not None else None
         B = h.shape[0]
 

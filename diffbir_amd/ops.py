@@ -176,10 +176,12 @@ _WS = {}       # device -> f32 split-K workspace (grown on demand, reused by eve
 
 
 def splitk_workspace(device, nbytes: int) -> T:
-    ws = _WS.get(device)
+    """One workspace per (device, stream): launches on different streams may run concurrently."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(max(nbytes, 64 << 20) // 4, dtype=torch.float32, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 

@@ -23,6 +23,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     pipe, cldm, swin = bench.build_engine(dev, torch.float16)
+    cldm.overlap_streams = False
     B2 = 2 * a.batch
     x = torch.randn(B2, 4, 64, 64, device=dev)
     cond = dict(c_txt=torch.randn(B2, 77, 1024, device=dev), c_img=torch.randn(B2, 4, 64, 64, device=dev))
