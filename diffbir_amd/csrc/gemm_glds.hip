@@ -91,19 +91,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   RAW: group 0 waits vmcnt(LOADS) after its staging (its share of tile k landed), group 1 waits vmcnt(0) after its
 //        multiply (its share of tile k, issued one interval earlier), both before the barrier that precedes the first
 //        read of tile k;  WAR: tile k+1 refills the slot of tile k-2, last read by group 1 two intervals earlier.
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE, int DEPH>
+// BKT = K depth of a tile (64, or 32: LDS rows of 64 B, 4 chunks; lets a 256x256 tile keep a 3-slot ring in 96 KB for
+// the de-phased schedule).
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE, int DEPH, int BKT>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses gfx950-only builtins (buffer descriptors, LDS-DMA, MFMA)
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-  constexpr int RPP = NT / 8;                  // tile rows covered by one glds pass of the whole block
+  constexpr int BK = BKT;                      // shadows the file-scope default inside the kernel
+  constexpr int ROWB = BK * 2, CPR = BK / 8;   // bytes / 16-byte chunks per LDS tile row
+  constexpr int KS = BK / 16;                  // MFMA k-steps per tile
+  constexpr int RPP = NT / CPR;                // tile rows covered by one glds pass of the whole block
   constexpr int PASS_BYTES = NT * 16;
   constexpr int RA = BM / RPP, RB = (BN + RPP - 1) / RPP;  // glds per thread per stage (activation / weight tile)
   constexpr int LOADS = RA + RB;
   // BN = 160 (NJ = 5) is not a multiple of the pass height: the weight region is rounded up to whole passes and the
   // rows past BN are fed from the zero page
   constexpr bool EXACT_B = DEPH && (BN % RPP != 0);  // DEPH needs 3 slots: no room for the round-up rows
-  constexpr int A_BYTES = BM * 128, B_BYTES = (EXACT_B ? BN : RB * RPP) * 128, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = (EXACT_B ? BN : RB * RPP) * ROWB, BUF_BYTES = A_BYTES + B_BYTES;
   static_assert(BM % RPP == 0, "activation tile rows must be a multiple of the pass height");
   static_assert(STAGES >= 2 && (STAGES - 1) * LOADS < 64, "vmcnt is 6 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,8 +137,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   const u16* __restrict__ Wg = reinterpret_cast<const u16*>(d.W) + (long long)bz * d.strideW_z;
 
   // ---- staging roles: thread handles LDS chunk position (row = (tid>>3) + RPP*i, cpos = tid&7) ----
-  const int srow = tid >> 3;
-  const int cch = ((tid & 7) ^ ((srow >> 1) & 7)) * 8;  // logical K offset (halfs) of the chunk this thread fetches
+  // swizzle key of a tile row: 128-byte rows (BK 64): (row >> 1) & 7 — two rows fill a 256-byte bank line; 64-byte rows
+  // (BK 32): (row >> 2) & 3 — four rows per bank line.  Either way the 16 lanes of a ds_read_b128 service group (rows
+  // distinct mod 16, same logical chunk) land in 16 distinct 16-byte slots.
+  const int srow = tid / CPR;
+  const int skey = BK == 64 ? ((srow >> 1) & 7) : ((srow >> 2) & 3);
+  const int cch = ((tid % CPR) ^ skey) * 8;  // logical K offset (halfs) of the chunk this thread fetches
   const bool conv = d.mode == DBIR_MODE_CONV3X3;
 
   // Operands are fetched with `buffer_load_dwordx4 ... lds` through two block-local buffer descriptors (SRD): the
@@ -289,9 +298,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     if (s < nk) STAGE();
 
   // fragment read offsets (bytes) inside a stage: row * 128 + ((2*ks + hi) ^ key(row)) * 16
-  const int a_frag = (wm * 32 * MI + lq) * 128;
-  const int b_frag = A_BYTES + (wn * 32 * NJ + lq) * 128;
-  const int sw = (lq >> 1) & 7;
+  const int a_frag = (wm * 32 * MI + lq) * ROWB;
+  const int b_frag = A_BYTES + (wn * 32 * NJ + lq) * ROWB;
+  const int sw = BK == 64 ? ((lq >> 1) & 7) : ((lq >> 2) & 3);
+  constexpr int FSTR = 32 * ROWB;  // bytes between consecutive 32-row MFMA blocks
 
   int c_slot = 0;
   if constexpr (DEPH) {
@@ -333,14 +343,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   do {                                                                                                        \
     const int co_ = ((2 * (KS) + hi) ^ sw) * 16;                                                              \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) wf[SET][j] =                                               \
-        *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * 4096 + co_);                           \
+        *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * FSTR + co_);                           \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) xf[SET][i] =                                               \
-        *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co_);                           \
+        *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * FSTR + co_);                           \
   } while (0)
         LOAD_FRAGS_D(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          if (ks < 3) LOAD_FRAGS_D(ks + 1, (ks + 1) & 1);
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks < KS - 1) LOAD_FRAGS_D(ks + 1, (ks + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < MI; ++i)
@@ -382,9 +392,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   do {                                                                                                        \
     const int co_ = ((2 * (KS) + hi) ^ sw) * 16;                                                              \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) wf[SET][j] =                                               \
-        *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * 4096 + co_);                           \
+        *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * FSTR + co_);                           \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) xf[SET][i] =                                               \
-        *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co_);                           \
+        *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * FSTR + co_);                           \
   } while (0)
       LOAD_FRAGS(0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -393,8 +403,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       if (kt + STAGES - 1 < nk && (!kDiag || p.debug != 1)) STAGE();
       if (kDiag && p.debug == 2) continue;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) LOAD_FRAGS(ks + 1, (ks + 1) & 1);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks < KS - 1) LOAD_FRAGS(ks + 1, (ks + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's reads ahead of this k-step's MFMAs
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -405,15 +415,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     } else {
       if (kDiag && p.debug == 2) continue;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const int co = ((2 * ks + hi) ^ sw) * 16;
         typename T::vec8 xf[MI], wf[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          wf[j] = *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * 4096 + co);
+          wf[j] = *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * FSTR + co);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-          xf[i] = *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * 4096 + co);
+          xf[i] = *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * FSTR + co);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -650,21 +660,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
   }
 }
 
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0>
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0, int BKT = 64>
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-  constexpr int RPP_ = 8 * WM * WN, BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
-  constexpr int ring = STAGES * (BM + BNR) * 128, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
+  constexpr int RPP_ = 64 * WM * WN / (BKT / 8), BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
+  constexpr int ring = STAGES * (BM + BNR) * BKT * 2, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
   constexpr int lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   constexpr int blocks_per_cu = (160 * 1024) / lds;
   constexpr int waves = WM * WN * (blocks_per_cu > 2 ? 2 : blocks_per_cu);
   constexpr int MINW = waves >= 8 ? 2 : 1;
-  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE, DEPH>;
+  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE, DEPH, BKT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
+  }
+  const dbir_gemm_desc& dd = p.d;
+  // K tiling of this variant (K / Cin are multiples of 64, checked by dbir_gemm_glds_eligible) and the split-K slices:
+  // whole K tiles, every slice non-empty
+  p.nkc = (dd.mode == DBIR_MODE_LINEAR ? dd.K : dd.Cin) / BKT;
+  {
+    const int nk_total = p.nkc * p.ntaps;
+    int sk = dd.splitk > 1 ? dd.splitk : 1;
+    if (sk > nk_total) sk = nk_total;
+    p.kt_per = cdiv(nk_total, sk);
+    p.splitk = cdiv(nk_total, p.kt_per);
+    if (p.debug == 5 && p.splitk > 1) p.debug = 0;  // the diagnostic timestamps share the workspace pointer
+    if (p.splitk > 1) {
+      const long long need = (long long)p.splitk * (dd.batch > 0 ? dd.batch : 1) * dd.M * dd.N * 4;
+      if (!dd.ws || dd.ws_bytes < need || (reinterpret_cast<uintptr_t>(dd.ws) & 15)) {
+        dbir_set_error("dbir_gemm: split-K %d needs a 16-byte aligned workspace of %lld bytes (got %lld)", p.splitk,
+                       need, dd.ws_bytes);
+        return DBIR_ERR_ARG;
+      }
+      if (dd.act == DBIR_ACT_GEGLU || dd.N % 8 != 0 || dd.ldc % 8 != 0) {
+        dbir_set_error("dbir_gemm: split-K needs N %% 8 == 0 and no GEGLU");
+        return DBIR_ERR_ARG;
+      }
+    }
   }
   p.mtiles = cdiv(p.d.M, BM);
   p.ntiles = cdiv(p.d.N, BN);
@@ -706,6 +740,9 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
     case 36: return launch2<T, 4, 2, 2, 2, 3, 1, 1>(p, s);  // 256x128
     case 37: return launch2<T, 8, 1, 1, 5, 3, 1, 1>(p, s);  // 256x160
     case 38: return launch2<T, 4, 2, 2, 1, 3, 1, 1>(p, s);  // 256x64
+    // K depth 32: the 256x256 tile fits a 3-slot ring (96 KB) -> de-phased / 4-slot lockstep variants
+    case 40: return launch2<T, 2, 4, 4, 2, 3, 1, 1, 32>(p, s);  // 256x256 de-phased
+    case 41: return launch2<T, 2, 4, 4, 2, 4, 1, 0, 32>(p, s);  // 256x256 lockstep, 4-slot ring
   }
   dbir_set_error("dbir_gemm: bad glds tile %d", tile);
   return DBIR_ERR_ARG;
@@ -742,13 +779,8 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
   p.d = dd;
   p.Hv = Hv;
   p.Wv = Wv;
-  if (dd.mode == DBIR_MODE_LINEAR) {
-    p.nkc = dd.K / BK;
-    p.ntaps = 1;
-  } else {
-    p.nkc = dd.Cin / BK;
-    p.ntaps = 9;
-  }
+  p.ntaps = dd.mode == DBIR_MODE_LINEAR ? 1 : 9;
+  p.nkc = 0;  // set per variant in launch2 (depends on the variant's K depth)
   p.vec_bias = dd.bias && (reinterpret_cast<uintptr_t>(dd.bias) & 15) == 0;
   p.vec_rv = dd.rowvec && (reinterpret_cast<uintptr_t>(dd.rowvec) & 7) == 0 && dd.rowvec_ld % 4 == 0;
   {
@@ -759,28 +791,9 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
     p.a_elems = dd.mode == DBIR_MODE_CONV3X3 ? (long long)dd.B * dd.Hi * dd.Wi * dd.Cin
                                              : (long long)(dd.M - 1) * dd.lda + dd.K;
   }
-  {
-    // split-K (explicit request only): slices of whole K tiles; every slice must be non-empty
-    const int nk_total = p.nkc * p.ntaps;
-    int sk = dd.splitk > 1 ? dd.splitk : 1;
-    if (sk > nk_total) sk = nk_total;
-    p.kt_per = cdiv(nk_total, sk);
-    p.splitk = cdiv(nk_total, p.kt_per);
-    p.ws = reinterpret_cast<float*>(dd.ws);
-    if (p.debug == 5 && p.splitk > 1) p.debug = 0;  // the diagnostic timestamps share the workspace pointer
-    if (p.splitk > 1) {
-      const long long need = (long long)p.splitk * (dd.batch > 0 ? dd.batch : 1) * dd.M * dd.N * 4;
-      if (!dd.ws || dd.ws_bytes < need || (reinterpret_cast<uintptr_t>(dd.ws) & 15)) {
-        dbir_set_error("dbir_gemm: split-K %d needs a 16-byte aligned workspace of %lld bytes (got %lld)", p.splitk,
-                       need, dd.ws_bytes);
-        return DBIR_ERR_ARG;
-      }
-      if (dd.act == DBIR_ACT_GEGLU || dd.N % 8 != 0 || dd.ldc % 8 != 0) {
-        dbir_set_error("dbir_gemm: split-K needs N %% 8 == 0 and no GEGLU");
-        return DBIR_ERR_ARG;
-      }
-    }
-  }
+  p.ws = reinterpret_cast<float*>(dd.ws);
+  p.splitk = 1;
+  p.kt_per = 0;
   if (tile == 0) {
     // Tile choice from the MI355X microbenchmarks (tools/bench_kernels.py, profiles/kbench_r1.json):
     //   256x256 (tile 10, 128x64 per wave: fewest LDS reads per MFMA) whenever N wastes <= 20 % of 256-wide column

@@ -92,7 +92,7 @@ typedef struct dbir_gemm_desc {
                16: 256x160 (4 waves) — 160-wide tiles fit the UNet's N = 320 k channel counts without padding;
                20 + t for t in {5, 6, 10, 12, 14, 15}: tile t with software-pipelined LDS fragment reads;
                36 / 37 / 38: de-phased two-group 256x128 / 256x160 / 256x64 (3-slot ring, staging of one wave group
-               overlaps the MFMAs of the other) */
+               overlaps the MFMAs of the other); 40 / 41: 256x256 with K depth 32 (3-slot de-phased / 4-slot lockstep) */
   /* split-K (tiles 5-12 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
    * into f32 partial sums in `ws` (>= splitk * batch * M * N * 4 bytes, 16-byte aligned, caller-owned), then a second
    * kernel sums the slices in a fixed order and applies the epilogue.  For small-M / huge-K problems (8x8 and 16x16

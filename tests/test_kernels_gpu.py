@@ -187,8 +187,8 @@ def test_conv3x3_fused_epilogue(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
-GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38]
-# 20 + t: tile t with pipelined fragment reads; 36-38: de-phased two-group variants
+GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41]
+# 20 + t: tile t with pipelined fragment reads; 36-38: de-phased two-group variants; 40/41: K depth 32 (256x256)
 NO_GEGLU_TILES = (14, 15, 16, 34, 35, 37, 38)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
 
 
@@ -350,7 +350,7 @@ def test_glds_splitk(code, dtype):
         ops.linear(xl, pl, tile=13 + 100 * 2)   # the phased kernel has no split-K
 
 
-@pytest.mark.parametrize("tile13", [13, 36, 37, 38])
+@pytest.mark.parametrize("tile13", [13, 36, 37, 38, 40, 41])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_phased_gemm_race_screen(dtype, tile13):
     """Tile 13 (two staggered wave groups, counted vmcnt across barriers) at full-chip sizes, repeated, against the
