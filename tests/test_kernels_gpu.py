@@ -379,6 +379,10 @@ def test_phased_gemm_race_screen(dtype, tile13):
     pw5 = ops.pack_conv3x3(rnd(200, 64, 3, 3, dtype=torch.float32, s=0.05, seed=13).cpu(), None, dtype, DEV)
     cases.append(("conv 8x33x47 64->200 s2", lambda t: ops.conv3x3(x5, pw5, stride=2, tile=t)))
     ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    if tile13 in (40, 41):
+        # K depth 32: a convolution's (channel slice, tap) visiting order differs from the K-depth-64 kernels, so the f32
+        # sums differ in the last bits before the 16-bit rounding — a few ulp, still orders of magnitude below a race
+        ulp *= 4
     for name, fn in cases:
         ref = fn(5).clone().float()
         for it in range(6):
