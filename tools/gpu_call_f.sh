@@ -15,3 +15,4 @@ mkdir -p gpurun_out/prof_f
 echo "rocprof rc=$? t=$(( $(date +%s) - T0 ))s"
 find gpurun_out/prof_f -name "*kernel_trace.csv" -delete
 sh tools/pmc_traffic.sh gpurun_out/pmc_f > gpurun_out/f_pmc.log 2>&1; echo "pmc rc=$? t=$(( $(date +%s) - T0 ))s"
+timeout 300 python tools/bench_tiled.py > gpurun_out/f_tiled.log 2>&1; echo "tiled rc=$? t=$(( $(date +%s) - T0 ))s"; tail -1 gpurun_out/f_tiled.log | cut -c1-400
