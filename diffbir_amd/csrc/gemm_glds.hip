@@ -1,29 +1,33 @@
-// Implicit-GEMM (linear / 1x1 / 3x3 convolution) on gfx950 MFMA, direct-to-LDS staged, multi-stage ring.
+// Implicit-GEMM (linear / 1x1 / 3x3 convolution) on gfx950 MFMA, direct-to-LDS staged, multi-slot ring.
 //
-// This is the hot kernel of the engine: every conv3x3 with Cin % 64 == 0 and every linear with K % 64 == 0
+// This is the hot kernel family of the engine: every conv3x3 with Cin % 64 == 0 and every linear with K % 64 == 0
 // of the UNet / ControlNet / VAE / SwinIR (i.e. all of them except the 4-/8-channel stem convs) runs here.
-// The generic register-staged kernel in gemm.hip remains as the fallback for the odd shapes and for the
-// f32 / transposed stores.
+// The generic register-staged kernel in gemm.hip remains as the fallback for the odd shapes and f32 stores.
 //
-// Structure (cdna_hip_programming.md §5 / T2 / T3+T4):
+// Structure (cdna_hip_programming.md §5 / T2 / T3+T4, re-derived for this engine's operand layout):
 //   * WM x WN wave64 per block, each wave owns a (32*MI) x (32*NJ) output tile of v_mfma_f32_32x32x16
-//     accumulators; BK = 64 halfs = one 128-byte line per tile row.  One template gives the 128x128 / 256x64
-//     (256 threads, 2 blocks per CU) and the 256x128 / 256x256 (1 block per CU, 3-/2-stage ring) variants.
-//   * Both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round trip).
-//     The LDS image is lane-linear, so the bank-conflict swizzle is applied on the SOURCE address: LDS chunk
-//     position `cpos` of row r holds logical 16-byte chunk `cpos ^ ((r >> 1) & 7)`; the MFMA fragment
-//     ds_read_b128 applies the same XOR (guide rule 21).  With 128-byte rows two consecutive rows fill one
-//     256-byte bank row, so this key makes the 16 lanes of every ds_read_b128 service group (16 distinct
-//     rows mod 16, same logical chunk) hit 16 distinct 16-byte slots: conflict-free.
-//   * conv3x3 is an implicit GEMM whose K order is (tap, channel); Cin % 64 == 0 makes every K tile lie inside
-//     one tap, so a tile row is one contiguous 128-byte run of the NHWC input at a per-row pixel offset that
-//     only changes when the tap changes.  Padding rows / taps outside the image read a 256-byte zero page.
-//   * STAGES-deep LDS ring, tiles t+1 .. t+STAGES-1 in flight while tile t is multiplied: counted
-//     `s_waitcnt vmcnt(N)` (never a drain in steady state) + ONE raw s_barrier per K tile.
+//     accumulators; K depth of a tile BKT = 64 halfs (one 128-byte line per tile row) or 32.  One template gives the
+//     128x128 / 256x64 / 64x256 / 256x128 / 256x256 and the 160-wide (256x160, 128x160: the UNet's channel counts are
+//     multiples of 320) tiles; see dispatch2() for the catalogue.
+//   * Both operand tiles go HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (16 B per lane, no VGPR round trip)
+//     through two block-local buffer descriptors: per-lane 32-bit offsets are computed once per block, the
+//     (tap, channel tile) part of a K tile is a scalar offset, and padding / out-of-tile rows use an out-of-range
+//     offset for which the hardware returns zeros.
+//     The LDS image is lane-linear, so the bank-conflict swizzle is applied on the SOURCE offset: LDS chunk
+//     position `cpos` of row r holds logical 16-byte chunk `cpos ^ key(r)` (key = (r >> 1) & 7 for 128-byte rows,
+//     (r >> 2) & 3 for 64-byte rows); the MFMA fragment ds_read_b128 applies the same XOR (guide rule 21), which
+//     makes the 16 lanes of every ds_read_b128 service group hit 16 distinct 16-byte slots: conflict-free.
+//   * conv3x3 is an implicit GEMM over K = (tap, channel); Cin % 64 == 0 makes every K tile lie inside one tap, so a
+//     tile row is one contiguous run of the NHWC input at a per-row pixel offset.  K tiles are visited tap-inner
+//     (the 9 taps of one channel slice consecutively: the shifted windows re-hit L2).
+//   * STAGES-slot LDS ring with counted `s_waitcnt vmcnt(N)` (never a drain in steady state) + raw s_barrier;
+//     PIPE = 1 software-pipelines the LDS fragment reads; DEPH = 1 runs the block's two wave groups half a K tile
+//     apart so that one group's staging burst (paced by the vector memory pipe) overlaps the other group's MFMAs.
 //   * MFMA orientation is D[n][m] (first operand = weight rows) so that a lane holds 4 consecutive output
 //     channels of one pixel: the f32 epilogue (bias, time-embedding row vector, SiLU/GELU/LeakyReLU/GEGLU,
 //     scale) runs in registers, the 16-bit tile is transposed through LDS and written with 16-byte row-contiguous
-//     stores (+ residual add on that side).
+//     stores (+ residual add on that side), or transposed per batch (V^T for the attention kernel).
+//   * Split-K: K slices computed by different workgroups into f32 slabs + a deterministic reduce/epilogue kernel.
 //   * blockIdx -> tile mapping is XCD-aware (bijective remap, guide T1): each XCD's L2 sees a contiguous
 //     range of tiles with the N tiles of one activation panel adjacent.
 #include <stdlib.h>
@@ -40,8 +44,6 @@ constexpr bool kDiag = true;
 constexpr bool kDiag = false;
 #endif
 
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];  // zero-initialised device memory
-
 struct G2Params {
   dbir_gemm_desc d;
   int Hv, Wv;   // virtual (upsampled) input extent for conv bounds checks
@@ -56,7 +58,6 @@ struct G2Params {
   int debug;             // DIAGNOSTIC (env DBIR_GEMM_DEBUG): 1 = skip steady-state staging, 2 = skip MFMAs
 };
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // exact-GELU with erf from Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the 16-bit output ulp):
