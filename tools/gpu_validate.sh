@@ -1,5 +1,6 @@
 #!/bin/bash
-# Full validation: -m gpu suite, smoke, bench (with cpu baseline), rocprofv3 kernel stats, PMC traffic.
+# Full validation on the GPU box (run through gpurun from the repo root): -m gpu suite, smoke, bench (with cpu baseline),
+# rocprofv3 kernel stats, PMC traffic, tiled 2048x2048 timing.  Outputs under gpurun_out/; summaries are copied to profiles/ by hand.
 cd "${GRAFT_REPO_ROOT:-.}"
 REPO=$PWD
 mkdir -p gpurun_out
