@@ -373,19 +373,36 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     }
 #undef TSD
     if (grp == 0) asm volatile("s_barrier" ::: "memory");  // pairs group 1's extra barrier
-  } else
+  } else {
+  // DIAGNOSTIC (kDiag build, debug == 5): per-wave s_memtime accumulators {vmcnt wait, barrier wait, first reads +
+  // stage issue, remaining reads + MFMA issue} -> workspace, read by tools/bench_one.py
+  unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tprev = 0;
+  const bool instr = kDiag && p.debug == 5;
+#define TSL(ACC)                                                   \
+  do {                                                             \
+    if (instr) {                                                   \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      ACC += now_ - tprev;                                         \
+      tprev = now_;                                                \
+    }                                                              \
+  } while (0)
+  if (instr) tprev = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = tprev;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed (this wave's share); later tiles may stay in flight
     if (kt + STAGES - 2 < nk)
       wait_vmcnt<(STAGES - 2) * LOADS>();
     else
       wait_vmcnt<0>();
+    TSL(tacc0);
     // every wave's share landed, and everyone is done reading the slot that is refilled next
     asm volatile("s_barrier" ::: "memory");
+    TSL(tacc1);
     const char* base = smem + c_slot * BUF_BYTES;
     c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
     if constexpr (!PIPE) {
       if (kt + STAGES - 1 < nk && (!kDiag || p.debug != 1)) STAGE();
+      TSL(tacc2);
     }
     if constexpr (PIPE) {
       typename T::vec8 xf[2][MI], wf[2][NJ];
@@ -402,6 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       // the next tile's direct-to-LDS loads are issued while the first fragment reads are in flight (the slot they
       // refill was last read before the barrier above)
       if (kt + STAGES - 1 < nk && (!kDiag || p.debug != 1)) STAGE();
+      TSL(tacc2);
       if (kDiag && p.debug == 2) continue;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -431,7 +449,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
           for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);  // D[n][m]
       }
     }
+    TSL(tacc3);
   }
+  if (instr && p.ws && lane == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + ((long long)blockIdx.x * (WM * WN) + wave) * 8;
+    o[0] = tacc0; o[1] = tacc1; o[2] = tacc2; o[3] = tacc3;
+    o[4] = __builtin_amdgcn_s_memtime() - tstart; o[5] = nk; o[6] = 0;
+  }
+#undef TSL
+  }  // lockstep path
 #undef STAGE
 
   const int N = d.N;
