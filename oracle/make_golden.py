@@ -2,6 +2,7 @@
 (/root/reference, CPU fp32) on seeded synthetic weights/inputs.  Run here (the GPU box has no reference):
 
     python -m oracle.make_golden tiny            # seconds..minutes
+    python -m oracle.make_golden tiny_options    # option paths of Pipeline.run on the tiny config
     python -m oracle.make_golden full_modules    # full-size nets, module level (a few minutes)
     python -m oracle.make_golden full_pipeline   # 1x512x512, 50 spaced steps + CFG (≈10 min on 8 cores)
 
@@ -43,12 +44,37 @@ def tokens_of(R, prompts):
 
 
 def run_pipeline(R, cldm, swin, diff, lq, steps, sampler, seed, cfg=4.0, tiled=False, tile=512, stride=256,
-                 cleaner_tiled=False):
+                 cleaner_tiled=False, strength=1.0, start="noise", noise_aug=0, rescale_cfg=False, pos=""):
     pipe = R.SwinIRPipeline(swin, cldm, diff, None, "cpu")
     torch.manual_seed(seed)
     with cases.quiet():
-        return pipe.run(lq, steps, 1.0, cleaner_tiled, 512, 256, False, 256, False, 256, tiled, tile, stride,
-                        "", cases.NEG_PROMPT, cfg, "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
+        return pipe.run(lq, steps, strength, cleaner_tiled, 512, 256, False, 256, False, 256, tiled, tile, stride,
+                        pos, cases.NEG_PROMPT, cfg, start, sampler, noise_aug, rescale_cfg, 0, 0, 300, 1, 1, 1)
+
+
+# option paths of Pipeline.run / apply_cldm (pipeline.py:146-174, 371-397; sampler.py:31-38): name -> (lq spec, kwargs)
+OPTION_CASES = {
+    "cond_start": ((3, 1, 512, 512), dict(steps=4, sampler="spaced", seed=7, start="cond")),
+    "noise_aug": ((3, 1, 512, 512), dict(steps=4, sampler="spaced", seed=7, noise_aug=120)),
+    "rescale_cfg": ((3, 1, 512, 512), dict(steps=4, sampler="spaced", seed=7, rescale_cfg=True, cfg=3.0)),
+    "cfg1": ((3, 1, 512, 512), dict(steps=4, sampler="spaced", seed=7, cfg=1.0)),
+    "strength": ((3, 1, 512, 512), dict(steps=4, sampler="dpm++_m2", seed=7, strength=0.6)),
+    "cleaner_tiled": ((9, 1, 600, 712), dict(steps=3, sampler="spaced", seed=5, cleaner_tiled=True)),
+    "small_upsized": ((13, 1, 300, 256), dict(steps=3, sampler="spaced", seed=5)),
+}
+
+
+@torch.no_grad()
+def gen_tiny_options(R):
+    from diffbir_amd import configs
+    cldm, swin, diff, W = build_reference(R, "tiny", configs.get("DIFFUSION_V21"))
+    g = {}
+    for name, (lqspec, kw) in OPTION_CASES.items():
+        kw = dict(kw)
+        g[name] = run_pipeline(R, cldm, swin, diff, cases.make_lq(*lqspec), kw.pop("steps"), kw.pop("sampler"),
+                               kw.pop("seed"), **kw)
+        print(name, g[name].shape)
+    np.savez_compressed(os.path.join(OUT, "tiny_options.npz"), **g)
 
 
 @torch.no_grad()
@@ -122,6 +148,8 @@ if __name__ == "__main__":
     if what == "tiny":
         gen_modules(R, "tiny", "tiny", 128, configs.get("DIFFUSION_V21"))
         gen_tiny_pipelines(R)
+    elif what == "tiny_options":
+        gen_tiny_options(R)
     elif what == "full_modules":
         gen_modules(R, "full", "full", 256, configs.get("DIFFUSION_V21"))
     elif what == "full_pipeline":

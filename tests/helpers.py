@@ -33,10 +33,29 @@ def build_engine(cfg_name: str, diffusion_cfg: str, device, dtype, W=None, raw_d
     return pipe, cldm, swin
 
 
-def run_pipe(pipe, lq, steps, sampler, seed, cfg=4.0, tiled=False, tile=512, stride=256, cleaner_tiled=False):
+def run_pipe(pipe, lq, steps, sampler, seed, cfg=4.0, tiled=False, tile=512, stride=256, cleaner_tiled=False,
+             strength=1.0, start="noise", noise_aug=0, rescale_cfg=False):
     pipe.randn = cases.NoiseStream(seed)
-    return pipe.run(lq, steps, 1.0, cleaner_tiled, 512, 256, False, 256, False, 256, tiled, tile, stride,
-                    "", cases.NEG_PROMPT, cfg, "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
+    return pipe.run(lq, steps, strength, cleaner_tiled, 512, 256, False, 256, False, 256, tiled, tile, stride,
+                    "", cases.NEG_PROMPT, cfg, start, sampler, noise_aug, rescale_cfg, 0, 0, 300, 1, 1, 1)
+
+
+# option paths of Pipeline.run (goldens: tests/golden/tiny_options.npz, oracle/make_golden.py OPTION_CASES)
+OPTION_CASES = {
+    "cond_start": ((3, 1, 512, 512), dict(steps=4, sampler="spaced", seed=7, start="cond")),
+    "noise_aug": ((3, 1, 512, 512), dict(steps=4, sampler="spaced", seed=7, noise_aug=120)),
+    "rescale_cfg": ((3, 1, 512, 512), dict(steps=4, sampler="spaced", seed=7, rescale_cfg=True, cfg=3.0)),
+    "cfg1": ((3, 1, 512, 512), dict(steps=4, sampler="spaced", seed=7, cfg=1.0)),
+    "strength": ((3, 1, 512, 512), dict(steps=4, sampler="dpm++_m2", seed=7, strength=0.6)),
+    "cleaner_tiled": ((9, 1, 600, 712), dict(steps=3, sampler="spaced", seed=5, cleaner_tiled=True)),
+    "small_upsized": ((13, 1, 300, 256), dict(steps=3, sampler="spaced", seed=5)),
+}
+
+
+def run_option_case(pipe, name):
+    lqspec, kw = OPTION_CASES[name]
+    kw = dict(kw)
+    return run_pipe(pipe, cases.make_lq(*lqspec), kw.pop("steps"), kw.pop("sampler"), kw.pop("seed"), **kw)
 
 
 def rel_err(a, b):

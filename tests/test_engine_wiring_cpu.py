@@ -10,7 +10,7 @@ import torch
 
 from oracle import cases
 from tests import emu_ops
-from tests.helpers import build_engine, rel_err, run_pipe
+from tests.helpers import OPTION_CASES, build_engine, rel_err, run_option_case, run_pipe
 
 
 @pytest.fixture()
@@ -60,6 +60,19 @@ def test_pipeline_vs_reference_golden(monkeypatch, golden_dir, name, dcfg, lqspe
     pipe, cldm, swin = build_engine("tiny", dcfg, torch.device("cpu"), torch.float32, raw_dtype=True)
     ref = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))[name]
     out = run_pipe(pipe, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+    assert out.shape == ref.shape and out.dtype == np.uint8
+    psnr = cases.psnr_u8(out, ref)
+    assert psnr > 60.0, psnr
+
+
+@pytest.mark.parametrize("name", sorted(OPTION_CASES))
+def test_pipeline_options_vs_reference_golden(monkeypatch, golden_dir, name):
+    """Option paths of Pipeline.run / apply_cldm (start_point_type, noise_aug, rescale_cfg, cfg 1.0, strength,
+    tiled cleaner, sub-512 input with the bicubic up/down resizes) against the unmodified reference."""
+    emu_ops.install(monkeypatch)
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", torch.device("cpu"), torch.float32, raw_dtype=True)
+    ref = np.load(os.path.join(golden_dir, "tiny_options.npz"))[name]
+    out = run_option_case(pipe, name)
     assert out.shape == ref.shape and out.dtype == np.uint8
     psnr = cases.psnr_u8(out, ref)
     assert psnr > 60.0, psnr

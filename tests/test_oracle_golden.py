@@ -90,3 +90,28 @@ def test_pipeline_matches_reference_golden(tiny, gm, golden_dir, name, dcfg, kw)
     # fp32 CPU on both sides: identical up to rounding at the u8 quantisation boundary
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())
     assert cases.psnr_u8(out, ref) > 70.0
+
+
+OPTION_KW = {
+    "cond_start": dict(lq=(3, 1, 512, 512), steps=4, sampler_type="spaced", seed=7, start_point_type="cond"),
+    "noise_aug": dict(lq=(3, 1, 512, 512), steps=4, sampler_type="spaced", seed=7, noise_aug=120),
+    "rescale_cfg": dict(lq=(3, 1, 512, 512), steps=4, sampler_type="spaced", seed=7, rescale_cfg=True, cfg_scale=3.0),
+    "cfg1": dict(lq=(3, 1, 512, 512), steps=4, sampler_type="spaced", seed=7, cfg_scale=1.0),
+    "strength": dict(lq=(3, 1, 512, 512), steps=4, sampler_type="dpm++_m2", seed=7, strength=0.6),
+    "cleaner_tiled": dict(lq=(9, 1, 600, 712), steps=3, sampler_type="spaced", seed=5, cleaner_tiled=True),
+    "small_upsized": dict(lq=(13, 1, 300, 256), steps=3, sampler_type="spaced", seed=5),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OPTION_KW))
+def test_pipeline_options_match_reference_golden(tiny, gm, golden_dir, name):
+    """the oracle's option paths (pipeline.py:146-174, 371-397; sampler.py:31-38) pinned to the reference itself."""
+    ref = np.load(os.path.join(golden_dir, "tiny_options.npz"))[name]
+    kw = dict(OPTION_KW[name])
+    lq = cases.make_lq(*kw.pop("lq"))
+    seed = kw.pop("seed")
+    kw.setdefault("cfg_scale", 4.0)
+    out = _pipe(tiny, gm, "DIFFUSION_V21").run(lq, neg_prompt=cases.NEG_PROMPT, randn=cases.NoiseStream(seed), **kw)
+    assert out.shape == ref.shape
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import cases
-from tests.helpers import build_engine, rel_err, run_pipe
+from tests.helpers import OPTION_CASES, build_engine, rel_err, run_option_case, run_pipe
 
 pytestmark = pytest.mark.gpu
 REPORT = {}
@@ -90,6 +90,20 @@ def test_tiny_pipeline_vs_reference_golden(golden_dir, name, dcfg, lqspec, steps
     REPORT[f"tiny_{name}_{dtype}"] = psnr
     print(name, dtype, f"PSNR {psnr:.2f} dB")
     assert out.shape == ref.shape and psnr >= min_psnr, psnr
+
+
+@pytest.mark.parametrize("name", sorted(OPTION_CASES))
+def test_tiny_pipeline_options_vs_reference_golden(golden_dir, name):
+    """option paths of Pipeline.run (start point, noise augmentation, CFG rescale / off, strength, tiled cleaner,
+    sub-512 input) on the HIP kernels against the unmodified reference (CPU fp32)."""
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    ref = np.load(os.path.join(golden_dir, "tiny_options.npz"))[name]
+    out = run_option_case(pipe, name)
+    psnr = cases.psnr_u8(out, ref)
+    REPORT[f"tiny_option_{name}_fp16"] = psnr
+    print(name, f"PSNR {psnr:.2f} dB")
+    assert out.shape == ref.shape and psnr >= 45.0, psnr
 
 
 def test_full_pipeline_50_steps_vs_reference_golden(golden_dir):
