@@ -3,6 +3,7 @@
 
     python -m oracle.make_golden tiny            # seconds..minutes
     python -m oracle.make_golden tiny_options    # option paths of Pipeline.run on the tiny config
+    python -m oracle.make_golden host_tables     # schedules / tile windows / blend weights from the reference's functions
     python -m oracle.make_golden full_modules    # full-size nets, module level (a few minutes)
     python -m oracle.make_golden full_pipeline   # 1x512x512, 50 spaced steps + CFG (≈10 min on 8 cores)
 
@@ -140,6 +141,56 @@ def gen_full_pipeline(R):
     print("full pipeline done in", dt, "s")
 
 
+def gen_host_tables(R):
+    """Host-side tables of the path, straight from the reference's own functions: timestep spacing, the spaced
+    sampler's registered buffers, the DPM-Solver discrete VP schedule, tile windows and blend weights."""
+    import importlib
+    import json
+    from diffbir_amd import configs
+    sp = importlib.import_module("diffbir.sampler.spaced_sampler")
+    dp = importlib.import_module("diffbir.sampler.dpm_solver_pytorch")
+    g = {"space_timesteps": {}, "spaced_tables": {}, "dpm": {}, "sliding_windows": {}, "gaussian_weights": {}}
+    for n in (1, 2, 3, 5, 7, 10, 20, 25, 50, 100, 250, 999, 1000):
+        g["space_timesteps"][str(n)] = sorted(int(x) for x in sp.space_timesteps(1000, str(n)))
+    g["space_timesteps"]["ddim50"] = sorted(int(x) for x in sp.space_timesteps(1000, "ddim50"))
+    for name in ("DIFFUSION_V2", "DIFFUSION_V21"):
+        diff = R.Diffusion(**configs.get(name))
+        for steps in (5, 50):
+            smp = R.SpacedSampler(diff.betas, diff.parameterization, rescale_cfg=False)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                smp.make_schedule(steps)
+            tb = {k: getattr(smp, k).double().numpy() for k in (
+                "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_mean_coef1", "posterior_mean_coef2")}
+            g["spaced_tables"][f"{name}_{steps}"] = {
+                "timesteps": [int(t) for t in smp.timesteps],
+                **{k: [None if not np.isfinite(x) else float(x) for x in v] for k, v in tb.items()}}
+        ns = dp.NoiseScheduleVP("discrete", betas=torch.tensor(diff.betas, dtype=torch.float32))
+        solver = dp.DPM_Solver(lambda x, t: x, ns, algorithm_type="dpmsolver++")
+        ts = solver.get_time_steps("time_uniform", ns.T, 1.0 / ns.total_N, 20, "cpu")
+        g["dpm"][name] = dict(total_N=int(ns.total_N), T=float(ns.T), t=[float(x) for x in ts],
+                              alpha=[float(x) for x in ns.marginal_alpha(ts)],
+                              std=[float(x) for x in ns.marginal_std(ts)],
+                              lam=[float(x) for x in ns.marginal_lambda(ts)],
+                              model_t=[float((x - 1.0 / ns.total_N) * 1000.0) for x in ts])
+    for (h, w, size, stride) in ((64, 64, 64, 32), (75, 89, 64, 32), (256, 256, 64, 32), (100, 64, 64, 48),
+                                 (600, 712, 512, 256)):
+        g["sliding_windows"][f"{h}x{w}_{size}_{stride}"] = [list(map(int, win))
+                                                             for win in R.common.sliding_windows(h, w, size, stride)]
+    for (tw, th) in ((64, 64), (512, 512), (32, 48)):
+        gw = R.common.gaussian_weights(tw, th).astype(np.float64)
+        if gw.size <= 4096:
+            g["gaussian_weights"][f"{tw}x{th}"] = dict(full=gw.tolist())
+        else:  # large tiles: a few rows / columns + the total (the weights are separable)
+            g["gaussian_weights"][f"{tw}x{th}"] = dict(
+                shape=list(gw.shape), total=float(gw.sum()),
+                rows={str(r): gw[r].tolist() for r in (0, th // 2 - 1, th // 2, th - 1)},
+                cols={str(c): gw[:, c].tolist() for c in (0, tw // 2 - 1, tw // 2, tw - 1)})
+    with open(os.path.join(OUT, "host_tables.json"), "w") as f:
+        json.dump(g, f)
+    print("host tables done", {k: len(v) for k, v in g.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     what = sys.argv[1]
@@ -148,6 +199,8 @@ if __name__ == "__main__":
     if what == "tiny":
         gen_modules(R, "tiny", "tiny", 128, configs.get("DIFFUSION_V21"))
         gen_tiny_pipelines(R)
+    elif what == "host_tables":
+        gen_host_tables(R)
     elif what == "tiny_options":
         gen_tiny_options(R)
     elif what == "full_modules":
