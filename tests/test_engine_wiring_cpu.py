@@ -76,3 +76,37 @@ def test_pipeline_options_vs_reference_golden(monkeypatch, golden_dir, name):
     assert out.shape == ref.shape and out.dtype == np.uint8
     psnr = cases.psnr_u8(out, ref)
     assert psnr > 60.0, psnr
+
+
+def test_pipeline_error_behaviour_matches_reference(engine):
+    """Error conventions of the drop-in boundary: ValueError on bad tile sizes (reference
+    pipeline.py:115,143,379), NotImplementedError on unknown samplers (pipeline.py:201)."""
+    pipe, cldm, swin = engine
+    lq = cases.make_lq(3, 1, 512, 512)
+
+    def run(img=None, **kw):
+        a = dict(steps=2, strength=1.0, cleaner_tiled=False, cleaner_tile_size=512, cleaner_tile_stride=256,
+                 vae_encoder_tiled=False, vae_encoder_tile_size=256, vae_decoder_tiled=False, vae_decoder_tile_size=256,
+                 cldm_tiled=False, cldm_tile_size=512, cldm_tile_stride=256, pos_prompt="", neg_prompt=cases.NEG_PROMPT,
+                 cfg_scale=4.0, start_point_type="noise", sampler_type="spaced", noise_aug=0, rescale_cfg=False,
+                 s_churn=0, s_tmin=0, s_tmax=300, s_noise=1, eta=1, order=1)
+        a.update(kw)
+        pipe.randn = cases.NoiseStream(1)
+        return pipe.run(lq if img is None else img, *a.values())
+
+    big = cases.make_lq(3, 1, 640, 640)
+    with pytest.raises(ValueError):
+        run(img=big, cldm_tiled=True, cldm_tile_size=520)             # not a multiple of 64 (latent 80 >= 65: stays tiled)
+    with pytest.raises(ValueError):
+        pipe.randn = cases.NoiseStream(1)
+        pipe.run(big, 2, 1.0, True, 520, 256, False, 256, False, 256, False, 512, 256, "", cases.NEG_PROMPT, 4.0, "noise",
+                 "spaced", 0, False, 0, 0, 300, 1, 1, 1)              # cleaner tile size not a multiple of 64
+    with pytest.raises(ValueError):
+        run(vae_encoder_tiled=True, vae_encoder_tile_size=300)        # not a multiple of 8
+    with pytest.raises(NotImplementedError):
+        run(sampler_type="no_such_sampler")
+    with pytest.raises(NotImplementedError):
+        run(sampler_type="edm_dpm++_3m_sde")                          # outside this engine's scope (DESIGN.md 7)
+    from diffbir_amd.pipeline import SwinIRPipeline
+    with pytest.raises(NotImplementedError):
+        SwinIRPipeline(swin, cldm, pipe.diffusion, cond_fn=object(), device="cpu")
