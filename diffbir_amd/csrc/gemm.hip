@@ -300,7 +300,6 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   if (d.rowvec) DBIR_CHECK_ARG(d.rows_per_batch > 0, "dbir_gemm: rowvec needs rows_per_batch");
   if (d.store_mode == 1) DBIR_CHECK_ARG(d.trans_L > 0 && !d.out_f32, "dbir_gemm: bad transposed store args");
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
-  if (d.act == DBIR_ACT_GEGLU16) DBIR_CHECK_ARG(d.N % 32 == 0, "dbir_gemm: GEGLU16 needs packed N %% 32 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
   DBIR_CHECK_ARG(tile >= 0 && tile <= 41, "dbir_gemm: bad tile %d", tile);
@@ -311,9 +310,6 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
     DBIR_CHECK_ARG(d.splitk <= 1 || (ok && tile != 13), "dbir_gemm: split-K is implemented by the direct-to-LDS "
                    "kernel only (tiles 5-12, eligible operands)");
     DBIR_CHECK_ARG(!(tile == 13 && d.store_mode != 0), "dbir_gemm: the phased kernel (tile 13) has no transposed store");
-    DBIR_CHECK_ARG(!(tile == 13 && d.act == DBIR_ACT_GEGLU16), "dbir_gemm: the phased kernel (tile 13) has no GEGLU16");
-    DBIR_CHECK_ARG(ok || d.act != DBIR_ACT_GEGLU16, "dbir_gemm: GEGLU16 is implemented by the direct-to-LDS kernel only "
-                   "(K %% 64 == 0, aligned operands)");
     if (ok && tile == 13) return dbir_gemm_ph(d, p.Hv, p.Wv, reinterpret_cast<hipStream_t>(stream));
     if (ok) return dbir_gemm_glds(d, p.Hv, p.Wv, tile, reinterpret_cast<hipStream_t>(stream));
   }

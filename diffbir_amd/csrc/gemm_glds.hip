@@ -482,11 +482,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     return;
   }
   // ---------------- epilogue: f32 math in registers -> 16-bit tile in LDS -> row-contiguous 16 B stores ----------
-  // GEGLU: value / gate interleaved per 32 packed columns (a wave's column blocks j = 0 / 1, NJ == 2 tiles only);
-  // GEGLU16: interleaved per 16 inside every 32-column MFMA block — a lane's register groups g = 0,1 hold value
-  // columns 8g+4hi.. and g = 2,3 the matching gate columns, so every tile shape (incl. the 160-wide ones) can gate.
-  const bool geglu = d.act == DBIR_ACT_GEGLU, geglu16 = d.act == DBIR_ACT_GEGLU16;
-  const int bn_out = (geglu || geglu16) ? BN / 2 : BN;
+  const bool geglu = d.act == DBIR_ACT_GEGLU;
+  const int bn_out = geglu ? BN / 2 : BN;
   const int cs_ld = bn_out + 8;  // halfs; (bn_out + 8) * 2 B is a multiple of 16
   u16* Cs = reinterpret_cast<u16*>(smem);
   const u16* __restrict__ RV = reinterpret_cast<const u16*>(d.rowvec);
@@ -524,7 +521,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       if (geglu && (j & 1)) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (geglu16 && g >= 2) continue;  // gate groups are consumed with their value groups
         const int nl = wn * 32 * NJ + j * 32 + 8 * g + 4 * hi;  // local packed column of element 0
         const int n0 = tn * BN + nl;
         float v[4] = {acc[i][j][4 * g + 0] + b4[j][g].x, acc[i][j][4 * g + 1] + b4[j][g].y,
@@ -559,15 +555,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= gelu_fast(gt[e]);
           }
-        } else if (geglu16) {
-          const int gg = g < 2 ? g + 2 : g;  // (constant after unrolling; g >= 2 never reaches this point)
-          const float gt[4] = {acc[i][j][4 * gg + 0] + b4[j][gg].x, acc[i][j][4 * gg + 1] + b4[j][gg].y,
-                               acc[i][j][4 * gg + 2] + b4[j][gg].z, acc[i][j][4 * gg + 3] + b4[j][gg].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= gelu_fast(gt[e]);
         }
-        const int ocl = geglu ? (wn * 16 * NJ + 8 * g + 4 * hi)
-                              : (geglu16 ? (wn * 16 * NJ + j * 16 + 8 * g + 4 * hi) : nl);
+        const int ocl = geglu ? (wn * 16 * NJ + 8 * g + 4 * hi) : nl;
         uint2 pk;
         pk.x = (uint32_t)T::from_f32(v[0] * d.out_scale) | ((uint32_t)T::from_f32(v[1] * d.out_scale) << 16);
         pk.y = (uint32_t)T::from_f32(v[2] * d.out_scale) | ((uint32_t)T::from_f32(v[3] * d.out_scale) << 16);
@@ -607,7 +596,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     return;
   }
   {
-    const int n_out = (geglu || geglu16) ? N / 2 : N;
+    const int n_out = geglu ? N / 2 : N;
     const int ch_per_row = bn_out >> 3;
     const int total = BM * ch_per_row;
     const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) + (long long)bz * d.strideR_z : nullptr;
@@ -732,7 +721,7 @@ int launch2(G2Params& p, hipStream_t s) {
                        need, dd.ws_bytes);
         return DBIR_ERR_ARG;
       }
-      if (dd.act == DBIR_ACT_GEGLU || dd.act == DBIR_ACT_GEGLU16 || dd.N % 8 != 0 || dd.ldc % 8 != 0) {
+      if (dd.act == DBIR_ACT_GEGLU || dd.N % 8 != 0 || dd.ldc % 8 != 0) {
         dbir_set_error("dbir_gemm: split-K needs N %% 8 == 0 and no GEGLU");
         return DBIR_ERR_ARG;
       }
@@ -792,7 +781,7 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
 bool dbir_gemm_glds_eligible(const dbir_gemm_desc& d) {
   if (d.out_f32) return false;
   if (d.store_mode == 1) {  // transposed store: whole 8-row chunks inside one batch, 16-byte aligned destinations
-    if (d.trans_L % 8 != 0 || d.trans_ld % 8 != 0 || d.trans_bstride % 8 != 0 || d.R || d.act == DBIR_ACT_GEGLU || d.act == DBIR_ACT_GEGLU16 ||
+    if (d.trans_L % 8 != 0 || d.trans_ld % 8 != 0 || d.trans_bstride % 8 != 0 || d.R || d.act == DBIR_ACT_GEGLU ||
         d.splitk > 1 || d.batch > 1)
       return false;
   } else if (d.store_mode != 0) {
@@ -809,7 +798,6 @@ bool dbir_gemm_glds_eligible(const dbir_gemm_desc& d) {
     if ((long long)d.B * d.Hi * d.Wi >= 2147483647LL) return false;
   }
   if (d.act == DBIR_ACT_GEGLU && d.N % 64 != 0) return false;
-  if (d.act == DBIR_ACT_GEGLU16 && d.N % 32 != 0) return false;
   return true;
 }
 
@@ -841,7 +829,7 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
     const int nt256 = cdiv(dd.N, 256);
     const bool fits256 = (nt256 * 256 - dd.N) * 5 <= nt256 * 256;
     const long long blocks256 = (long long)cdiv(dd.M, 256) * nt256 * (dd.batch > 0 ? dd.batch : 1);
-    if (dd.act == DBIR_ACT_GEGLU || dd.act == DBIR_ACT_GEGLU16 || (fits256 && blocks256 >= 150))
+    if (dd.act == DBIR_ACT_GEGLU || (fits256 && blocks256 >= 150))
       tile = 10;
     else if (dd.M >= 4096)
       tile = 12;

@@ -41,7 +41,6 @@ class _DiffusionNet(NativeModule):
         self.cfg = dict(cfg)
         self.plan = UNetPlan(cfg, hint_channels=hint_channels)
         self.dtype = torch.float32  # reference attribute (cast_dtype sets it); engine dtype is self._dtype
-        self.use_geglu16 = True     # packing of the GEGLU projections (see _pack_attn)
         self._ctx_cache: Dict[tuple, list] = {}
 
     # ------------------------------------------------------------------ packing
@@ -83,11 +82,8 @@ class _DiffusionNet(NativeModule):
         a.k2 = self._pk_lin(f"{q}.attn2.to_k", bias=False)
         a.v2 = self._pk_lin(f"{q}.attn2.to_v", bias=False)
         a.out2 = self._pk_lin(f"{q}.attn2.to_out.0")
-        # GEGLU projection: the 16-interleaved packing lets the autotuner use every tile shape (160-wide / de-phased);
-        # it needs the direct-to-LDS kernel (K % 64 == 0), else the 32-interleaved form the generic kernel also handles
-        wff, bff = self._w(f"{q}.ff.net.0.proj.weight"), self._w(f"{q}.ff.net.0.proj.bias")
-        pack_ff = ops.pack_geglu16 if (ch % 64 == 0 and (wff.shape[0] // 2) % 16 == 0 and self.use_geglu16) else ops.pack_geglu
-        a.ff1 = pack_ff(wff, bff, self._dtype, self._device)
+        a.ff1 = ops.pack_geglu(self._w(f"{q}.ff.net.0.proj.weight"), self._w(f"{q}.ff.net.0.proj.bias"), self._dtype,
+                               self._device)
         a.ff2 = self._pk_lin(f"{q}.ff.net.2")
         a.ctx_idx = len(self._attn_layers)
         self._attn_layers.append(a)

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DBIR_HIP_LIB", os.path.join(_HERE, "libdbir_hip.so"))
 
 F16, BF16 = 0, 1
-ACT_NONE, ACT_SILU, ACT_GELU, ACT_LRELU, ACT_GEGLU, ACT_GEGLU16 = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_LRELU, ACT_GEGLU = 0, 1, 2, 3, 4
 MODE_LINEAR, MODE_CONV3X3 = 0, 1
 
 

@@ -18,8 +18,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import native, tuning
-from .native import (ACT_GEGLU, ACT_GEGLU16, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_SILU, MODE_CONV3X3,  # noqa: F401
-                     MODE_LINEAR,
+from .native import (ACT_GEGLU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_SILU, MODE_CONV3X3, MODE_LINEAR,  # noqa: F401
                      GemmDesc)
 
 T = torch.Tensor
@@ -78,8 +77,7 @@ class PackedWeight:
     Kpad: int
     n_out: int                # columns actually written
     cin: int = 0              # conv3x3: (padded) input channels
-    geglu: bool = False       # value / gate interleaved per 32 packed columns (ACT_GEGLU)
-    geglu16: bool = False     # value / gate interleaved per 16 inside each 32-column block (ACT_GEGLU16)
+    geglu: bool = False
 
 
 def _finish_pack(w2d: T, bias: Optional[T], dtype, device, n_out=None, cin=0, geglu=False) -> PackedWeight:
@@ -121,23 +119,6 @@ def pack_geglu(w: T, bias: T, dtype, device) -> PackedWeight:
     bv, bg = bias.float()[:nh].reshape(nh // 32, 32), bias.float()[nh:].reshape(nh // 32, 32)
     bi = torch.stack([bv, bg], dim=1).reshape(N2)
     return _finish_pack(wi, bi, dtype, device, n_out=nh, geglu=True)
-
-
-def pack_geglu16(w: T, bias: T, dtype, device) -> PackedWeight:
-    """GEGLU projection [2*Nh, K] -> rows interleaved in blocks of 16 (16 value rows, 16 gate rows per 32-row MFMA
-    block): a lane's accumulator register groups g and g+2 then hold matching value / gate columns, so the gate can be
-    applied by every tile shape of the direct-to-LDS kernel (include/dbir.h DBIR_ACT_GEGLU16)."""
-    w = w.float()
-    N2, K = w.shape
-    nh = N2 // 2
-    assert nh % 16 == 0, "GEGLU16 half width must be a multiple of 16"
-    val, gate = w[:nh].reshape(nh // 16, 16, K), w[nh:].reshape(nh // 16, 16, K)
-    wi = torch.stack([val, gate], dim=1).reshape(N2, K)
-    bv, bg = bias.float()[:nh].reshape(nh // 16, 16), bias.float()[nh:].reshape(nh // 16, 16)
-    bi = torch.stack([bv, bg], dim=1).reshape(N2)
-    pw = _finish_pack(wi, bi, dtype, device, n_out=nh, geglu=False)
-    pw.geglu16 = True
-    return pw
 
 
 def pack_conv3x3(w: T, bias: Optional[T], dtype, device, cin_pad_to: int = 8, n_pad_to: int = 1) -> PackedWeight:
@@ -229,7 +210,7 @@ def _gemm_launch(d: GemmDesc, keep):
     # algorithmic HBM bytes: every operand once (conv input once, not once per tap), 16-bit
     z = max(d.batch, 1)
     a_elems = float(d.B) * d.Hi * d.Wi * d.Cin if d.mode == MODE_CONV3X3 else float(d.M) * d.K
-    n_st = d.N // 2 if d.act in (ACT_GEGLU, ACT_GEGLU16) else d.N
+    n_st = d.N // 2 if d.act == ACT_GEGLU else d.N
     nbytes = z * (2.0 * a_elems + 2.0 * d.N * d.K + (4.0 if d.out_f32 else 2.0) * d.M * n_st
                   + (2.0 * d.M * n_st if d.R else 0.0))
     with _Timed("gemm", 2.0 * d.M * (d.N) * d.K * z, tag, nbytes):
@@ -261,8 +242,6 @@ def linear(x: T, pw: PackedWeight, out: Optional[T] = None, act: int = ACT_NONE,
     assert K == pw.K, f"K mismatch: x has {K}, weight has {pw.K}"
     if pw.geglu:
         act = ACT_GEGLU
-    elif pw.geglu16:
-        act = ACT_GEGLU16
     if out is None:
         out = torch.empty(x.shape[:-1] + (pw.n_out,), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     assert out.shape[-1] == pw.n_out and _rows(out) == M

@@ -30,8 +30,6 @@ extern "C" {
 #define DBIR_ACT_GELU 2   /* exact erf GELU (F.gelu default) */
 #define DBIR_ACT_LRELU 3  /* LeakyReLU(act_param) */
 #define DBIR_ACT_GEGLU 4  /* x * gelu(gate): weights packed value/gate interleaved per 32 columns */
-#define DBIR_ACT_GEGLU16 5 /* same, interleaved per 16 columns inside every 32-column block: works with every tile shape
-                              of the direct-to-LDS kernel (tiles 5-12, 14-41); packed N % 32 == 0 */
 
 #define DBIR_MODE_LINEAR 0
 #define DBIR_MODE_CONV3X3 1

@@ -13,8 +13,8 @@ import torch
 import torch.nn.functional as F
 
 from diffbir_amd import ops as real_ops
-from diffbir_amd.ops import (ACT_GEGLU, ACT_GEGLU16, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_SILU, PackedWeight,  # noqa: F401
-                             pack_conv3x3, pack_geglu, pack_geglu16, pack_linear)
+from diffbir_amd.ops import (ACT_GEGLU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_SILU, PackedWeight,  # noqa: F401
+                             pack_conv3x3, pack_geglu, pack_linear)
 
 T = torch.Tensor
 
@@ -41,10 +41,6 @@ def _epilogue(acc: T, pw: Optional[PackedWeight], act, act_param, out_scale, res
         n2 = acc.shape[1]
         blk = acc.reshape(M, n2 // 64, 2, 32)
         acc = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(M, n2 // 2)
-    elif act == ACT_GEGLU16:
-        n2 = acc.shape[1]
-        blk = acc.reshape(M, n2 // 32, 2, 16)
-        acc = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(M, n2 // 2)
     else:
         acc = _act(acc, act, act_param)
     acc = acc * out_scale
@@ -59,8 +55,6 @@ def linear(x, pw, out=None, act=ACT_NONE, act_param=0.0, out_scale=1.0, residual
     assert K == pw.K
     if pw.geglu:
         act = ACT_GEGLU
-    elif pw.geglu16:
-        act = ACT_GEGLU16
     M = x.numel() // K if x.is_contiguous() else real_ops._rows(x)
     acc = x.reshape(-1, K).float() @ pw.w[: pw.N, :K].float().t()
     res = _epilogue(acc, pw, act, act_param, out_scale, residual, rowvec, rows_per_batch)[:, : pw.n_out]

@@ -242,31 +242,6 @@ def test_glds_geglu(M, Nh, K, tile, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [t for t in GLDS_TILES if t != 13])
-@pytest.mark.parametrize("M,Nh,K", [(512, 1280, 320), (100, 64, 64), (333, 96, 128), (4096, 2560, 640)])
-def test_glds_geglu16(M, Nh, K, tile, dtype):
-    """GEGLU with the 16-interleaved packing (DBIR_ACT_GEGLU16): every tile shape of the direct-to-LDS kernel."""
-    x = rnd(M, K, dtype=dtype)
-    w, b = rnd(2 * Nh, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(2 * Nh, dtype=torch.float32, seed=2)
-    pw = ops.pack_geglu16(w.cpu(), b.cpu(), dtype, DEV)
-    # independent statement of GEGLU on the UNPACKED weights (checks the packing interleave too)
-    h = x.float() @ w.to(dtype).float().t() + b
-    ref = (h[:, :Nh] * torch.nn.functional.gelu(h[:, Nh:])).to(dtype)
-    check(f"glds geglu16 {M}x{Nh}x{K} t{tile}", ops.linear(x, pw, tile=tile), ref, dtype)
-    res = rnd(M, Nh, dtype=dtype, seed=5)
-    out = torch.zeros(M, Nh + 24, dtype=dtype, device=DEV)
-    ref2 = torch.zeros_like(out)
-    ops.linear(x, pw, residual=res, out=out[:, 8:8 + Nh], tile=tile)
-    emu.linear(x, pw, residual=res, out=ref2[:, 8:8 + Nh])
-    check("glds geglu16+res into a view", out, ref2, dtype, 1.5)
-    if tile == GLDS_TILES[0]:
-        with pytest.raises(Exception):
-            ops.linear(x, pw, tile=13)      # the phased kernel only knows the 32-interleaved form
-        with pytest.raises(Exception):
-            ops.linear(x, pw, tile=210)     # no split-K with a gated epilogue
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("tile", GLDS_TILES)
 @pytest.mark.parametrize("Bz,L,N,K", [(2, 64, 128, 64), (2, 1024, 640, 640), (3, 200, 320, 320), (1, 4096, 320, 320)])
 def test_glds_linear_transposed(Bz, L, N, K, tile, dtype):

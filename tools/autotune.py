@@ -67,7 +67,7 @@ class Tuner:
         rec["us"]["0"] = self._time(d)
         cands = list(self.cands)
         # split-K only where the output tiles alone cannot fill the chip and K is deep (16x16 / 8x8 latent levels)
-        if (d.M * d.N <= 160 * 256 * 256 and d.K >= 1280 and d.N % 8 == 0 and d.act not in (ops.ACT_GEGLU, ops.ACT_GEGLU16)
+        if (d.M * d.N <= 160 * 256 * 256 and d.K >= 1280 and d.N % 8 == 0 and d.act != ops.ACT_GEGLU
                 and d.store_mode == 0 and "splitk" not in self.exclude):
             cands += [t + 100 * k for t, k in SPLITK if t not in self.exclude]
         for c in cands:
