@@ -277,12 +277,24 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
   commit(0, 0);
   __syncthreads();
 
+#ifdef DBIR_DIAG  // tile-loop anatomy (tools/attn_diag.py): s_memtime accumulators per section
+  unsigned long long ta[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define ATS(I)                                                    \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    ta[I] += now_ - tprev;                                        \
+    tprev = now_;                                                 \
+  } while (0)
+#else
+#define ATS(I)
+#endif
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * KT;
     const u16* Ks = lds + (kt & 1) * (KS_HALFS + VS_HALFS);
     const u16* Vs = Ks + KS_HALFS;
     const bool more = kt + 1 < ntiles;
     if (more) fetch(kt + 1);  // in flight during this tile's MFMAs
+    ATS(0);
 
     f32x16 s_acc[2];
 #pragma unroll
@@ -296,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
         s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
       }
     }
+    ATS(1);
     if (key0 + KT > Lk) {  // ragged last tile: mask keys >= Lk (wave-uniform branch)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -334,6 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
       }
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
+    ATS(2);
 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -351,9 +365,25 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
         o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
       }
     }
+    ATS(3);
     if (more) commit((kt + 1) & 1, kt + 1);  // the other buffer was last read in iteration kt-1 (barrier since)
+    ATS(4);
     __syncthreads();
+    ATS(5);
   }
+#ifdef DBIR_DIAG
+  // DIAG build only: the accumulators replace the first output row of this wave's 32-row slab — the harness
+  // (tools/attn_diag.py) reads them back from O and does not look at the attention result.  s_memtime does not order
+  // vector instructions, so only the fetch / commit / barrier sections are reliable; MFMA + softmax issue is the rest.
+  if (lane == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(O + (long long)b * o_bs +
+                                                                 (long long)(qb * 128 + wave * 32) * ldo + h * 64);
+    for (int i = 0; i < 6; ++i) o[i] = ta[i];
+    o[6] = ntiles;
+  }
+  return;
+#endif
+#undef ATS
 
   if (q_ok) {
     const float inv = 1.0f / l_run;
