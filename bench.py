@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--selftest", action="store_true",
+                    help="CPU / gloo dry run of the launch, barrier, max-over-ranks and JSON plumbing with a fake "
+                         "workload (tests/test_bench_plumbing_cpu.py); never a measurement")
     return ap.parse_args()
 
 
@@ -177,32 +180,47 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-    from diffbir_amd import native
-    native.lib()
-    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    pipe, cldm, swin = build_engine(device, dtype)
-    rs = np.random.RandomState(100 + rank)
-    lq = rs.randint(0, 256, (args.batch, 512, 512, 3)).astype(np.uint8)
-    lq_dev = torch.as_tensor(lq).to(device)          # inputs resident in HBM before the timed region
-    torch.manual_seed(231 + rank)
+    if args.selftest:
+        device, sync = torch.device("cpu"), (lambda: None)
+        if world > 1:
+            dist.init_process_group("gloo")
+        dtype = torch.float16
+        pipe = cldm = swin = None
+        lq_dev = None
+
+        def run_step():
+            time.sleep(0.02 * (1 + rank))  # ranks differ: the reported time must be the slowest rank's
+            return np.zeros((args.batch, 512, 512, 3), dtype=np.uint8)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        torch.cuda.set_device(local)
+        device, sync = torch.device("cuda", local), torch.cuda.synchronize
+        if world > 1:
+            dist.init_process_group("nccl", device_id=device)
+        from diffbir_amd import native
+        native.lib()
+        dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+        pipe, cldm, swin = build_engine(device, dtype)
+        rs = np.random.RandomState(100 + rank)
+        lq = rs.randint(0, 256, (args.batch, 512, 512, 3)).astype(np.uint8)
+        lq_dev = torch.as_tensor(lq).to(device)          # inputs resident in HBM before the timed region
+        torch.manual_seed(231 + rank)
+
+        def run_step():
+            return run_once(pipe, lq_dev, args.sampler_steps)
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(args.warmup):
-        run_once(pipe, lq_dev, args.sampler_steps)
+        run_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = run_once(pipe, lq_dev, args.sampler_steps)
+        out = run_step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -222,11 +240,13 @@ def main():
                    "global_batch": args.batch * world, "sampler_steps": args.sampler_steps, "parallelism": f"dp{world}"},
         "mfma_frac_end_to_end": value * FLOPS_PER_IMAGE * (args.sampler_steps / 50.0) / (world * MFMA_PEAK),
     }
-    if rank == 0 and not args.no_roofline:
+    if args.selftest:
+        res["data"] = "SELFTEST (fake workload, CPU/gloo) - not a measurement"
+    if rank == 0 and not args.no_roofline and not args.selftest:
         res["roofline"] = measure_roofline(cldm, device, args.batch)
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.selftest:
         del pipe, cldm, swin
         torch.cuda.empty_cache()
         res["cpu_baseline"] = cpu_baseline(args.batch)
