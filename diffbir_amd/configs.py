@@ -53,3 +53,18 @@ TINY_SWINIR = dict(img_size=64, patch_size=1, in_chans=3, embed_dim=60, depths=[
 
 def get(name: str) -> dict:
     return copy.deepcopy(globals()[name])
+
+
+_YAML = {
+    "cldm": ("diffbir.model.ControlLDM", "FULL_CLDM"),
+    "swinir": ("diffbir.model.SwinIR", "FULL_SWINIR"),
+    "diffusion": ("diffbir.model.Diffusion", "DIFFUSION_V2"),
+    "diffusion_v2.1": ("diffbir.model.Diffusion", "DIFFUSION_V21"),
+}
+
+
+def yaml_config(name: str) -> dict:
+    """The `{target, params}` tree of the reference's configs/inference/<name>.yaml (targets in the reference's
+    `diffbir.model.*` namespace, which `instantiate_from_config` resolves to this package)."""
+    target, key = _YAML[name]
+    return dict(target=target, params=get(key))

@@ -4,13 +4,21 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
-if [ -n "$DBIR_DIAG" ]; then FLAGS="$FLAGS -DDBIR_DIAG"; rm -f build/gemm_glds.o build/gemm_ph.o; fi
+if [ -n "$DBIR_DIAG" ]; then FLAGS="$FLAGS -DDBIR_DIAG"; fi
+SRCS="api gemm gemm_glds gemm_halo attention norm elementwise swin"
 mkdir -p build
-for f in api gemm gemm_glds gemm_ph attention norm elementwise swin; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/dbir.h -nt build/$f.o ]; then
+# objects built with a different flag set (e.g. a DBIR_DIAG build) must not be linked into this one
+if [ "$(cat build/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f build/*.o; echo "$FLAGS" > build/.flags; fi
+PIDS=""
+for f in $SRCS; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_epilogue.h -nt build/$f.o ] || [ ../../include/dbir.h -nt build/$f.o ]; then
+    rm -f build/$f.o
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    PIDS="$PIDS $!"
   fi
 done
-wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC build/api.o build/gemm.o build/gemm_glds.o build/gemm_ph.o build/attention.o build/norm.o build/elementwise.o build/swin.o -o ../libdbir_hip.so
+for p in $PIDS; do wait $p || { echo "build.sh: a hipcc job failed" >&2; exit 1; }; done
+OBJS=""
+for f in $SRCS; do OBJS="$OBJS build/$f.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o ../libdbir_hip.so
 echo "built $(pwd)/../libdbir_hip.so"

@@ -271,8 +271,9 @@ int dispatch(const GemmParams& p, int tile, hipStream_t s) {
 // direct-to-LDS variant (gemm_glds.hip)
 bool dbir_gemm_glds_eligible(const dbir_gemm_desc& d);
 int dbir_gemm_glds(const dbir_gemm_desc& d, int Hv, int Wv, int tile, hipStream_t s);
-// phased two-group 256x256 kernel (gemm_ph.hip), tile 13
-int dbir_gemm_ph(const dbir_gemm_desc& d, int Hv, int Wv, hipStream_t s);
+// halo-patch 3x3 convolution kernel (gemm_halo.hip), tiles 50 / 51
+bool dbir_gemm_halo_eligible(const dbir_gemm_desc& d, int tile);
+int dbir_gemm_halo(const dbir_gemm_desc& d, int tile, hipStream_t s);
 
 extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   DBIR_CHECK_ARG(dd && dd->A && dd->W && dd->C, "dbir_gemm: null pointer");
@@ -302,15 +303,19 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 41, "dbir_gemm: bad tile %d", tile);
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 59 && tile != 13, "dbir_gemm: bad tile %d", tile);
   if (tile == 0 || tile >= 5) {
     const bool ok = dbir_gemm_glds_eligible(d);
     DBIR_CHECK_ARG(ok || tile == 0, "dbir_gemm: tile %d (direct-to-LDS kernel) needs K/Cin %% 64 == 0, 16-byte aligned "
                    "operands and a 16-bit row-major output", tile);
-    DBIR_CHECK_ARG(d.splitk <= 1 || (ok && tile != 13), "dbir_gemm: split-K is implemented by the direct-to-LDS "
-                   "kernel only (tiles 5-12, eligible operands)");
-    DBIR_CHECK_ARG(!(tile == 13 && d.store_mode != 0), "dbir_gemm: the phased kernel (tile 13) has no transposed store");
-    if (ok && tile == 13) return dbir_gemm_ph(d, p.Hv, p.Wv, reinterpret_cast<hipStream_t>(stream));
+    DBIR_CHECK_ARG(d.splitk <= 1 || ok, "dbir_gemm: split-K is implemented by the direct-to-LDS kernels only "
+                   "(tiles >= 5, eligible operands)");
+    if (tile >= 50) {
+      DBIR_CHECK_ARG(ok && d.store_mode == 0 && dbir_gemm_halo_eligible(d, tile),
+                     "dbir_gemm: tile %d (halo-patch kernel) needs a stride-1 pad-1 3x3 convolution with Cin %% 64 == 0 "
+                     "whose 256-row tiles are whole image rows", tile);
+      return dbir_gemm_halo(d, tile, reinterpret_cast<hipStream_t>(stream));
+    }
     if (ok) return dbir_gemm_glds(d, p.Hv, p.Wv, tile, reinterpret_cast<hipStream_t>(stream));
   }
   DBIR_CHECK_ARG(d.splitk <= 1, "dbir_gemm: split-K needs the direct-to-LDS kernel (tile 5-12)");

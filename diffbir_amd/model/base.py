@@ -18,6 +18,7 @@ class NativeModule:
         self._device = torch.device("cpu")
         self._dtype = torch.float16
         self._packed = False
+        self._gen = 0  # bumped whenever the packed weights are rebuilt (captured HIP graphs key on it)
         self.training = False
 
     # ---- nn.Module-like surface -------------------------------------------------------------
@@ -85,6 +86,7 @@ class NativeModule:
                 raise RuntimeError(f"{type(self).__name__}: weights not loaded (e.g. {need[:3]})")
             self._pack()
             self._packed = True
+            self._gen += 1
 
     def _pack(self):  # pragma: no cover - abstract
         raise NotImplementedError

@@ -4,6 +4,9 @@ Keeps the reference surface: ``forward(x_noisy, t, cond)``, 
 ``vae_encode``, ``vae_decode``, ``cast_dtype``, ``load_pretrained_sd``, ``load_controlnet_from_ckpt``,
 ``control_scales``, ``eval()``, ``to()``; samplers may re-bind ``model.forward`` (tiling).
 """
+import os
+import warnings
+from collections import OrderedDict
 from typing import Dict, List, Set, Tuple
 
 import torch
@@ -30,6 +33,15 @@ class ControlLDM:
         # The two networks have the same shapes, and the 16x16 / 8x8 latent levels alone cannot fill 256 CUs.
         self.overlap_streams = True
         self._side_stream = {}
+        # engine option (off by default): capture one network evaluation (ControlNet + UNet, ~700 kernel launches from
+        # Python through ctypes) into a HIP graph per (shape, text context, control scales) and replay it every sampling
+        # step.  Measured on the batch-8 benchmark (profiles/r2_idle_gaps.json): with eager launches the GPU is already
+        # busy 98.2 % of the sampling loop (the host stays ahead; two streams), and replay is not faster (5.69 vs
+        # 5.84 img/s) — it pays only when the host is the bottleneck (small batches, slow hosts).  DBIR_GRAPH=1 enables.
+        self.use_graph = os.environ.get("DBIR_GRAPH", "0") == "1"
+        self._graphs: "OrderedDict[tuple, _EvalGraph]" = OrderedDict()
+        self._graph_pool = None
+        self.max_graphs = 6
 
     # ---- weights ------------------------------------------------------------------------------
     @torch.no_grad()
@@ -96,6 +108,41 @@ class ControlLDM:
     # ---- network evaluation ---------------------------------------------------------------------
     def forward(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
         """reference cldm.py:160-172. x f32 [B,4,h,w], t [B] (int or fractional), cond {c_txt, c_img} -> f32."""
+        from .. import ops
+        if self.use_graph and x_noisy.is_cuda and ops._PROFILE is None and ops._TUNER is None \
+                and not torch.cuda.is_current_stream_capturing():
+            return self._forward_graphed(x_noisy, t, cond)
+        return self._forward_eager(x_noisy, t, cond)
+
+    def _forward_graphed(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
+        """Replay (or capture) the HIP graph of this evaluation.  Static inputs: x, t, c_img (copied in); the text
+        context is part of the key (its cross-attention K / V^T are cached device tensors the graph reads)."""
+        c_txt, c_img = cond["c_txt"], cond["c_img"]
+        self.unet._ensure_packed()
+        self.controlnet._ensure_packed()
+        key = (tuple(x_noisy.shape), str(x_noisy.device), c_txt.data_ptr(), tuple(c_txt.shape), c_txt._version,
+               tuple(float(s) for s in self.control_scales), str(self.unet._dtype), bool(self.overlap_streams),
+               self.unet._gen, self.controlnet._gen)
+        g = self._graphs.get(key)
+        if g is None:
+            try:
+                g = _EvalGraph(self, x_noisy, t, c_txt, c_img)
+            except Exception as e:  # capture not possible here: keep launching the same kernels eagerly
+                warnings.warn(f"diffbir_amd: HIP graph capture of the network evaluation failed ({e!r}); "
+                              "continuing with eager launches")
+                self.use_graph = False
+                return self._forward_eager(x_noisy, t, cond)
+            self._graphs[key] = g
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.popitem(last=False)
+        else:
+            self._graphs.move_to_end(key)
+        return g.run(x_noisy, t, c_img)
+
+    def reset_graphs(self):
+        self._graphs.clear()
+
+    def _forward_eager(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
         c_txt, c_img = cond["c_txt"], cond["c_img"]
         if not (self.overlap_streams and x_noisy.is_cuda):
             control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales)
@@ -115,3 +162,33 @@ class ControlLDM:
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
+
+
+class _EvalGraph:
+    """One captured network evaluation.  All activations live in the graph's private memory pool (shared by every
+    graph of one ControlLDM: they are replayed one at a time on one stream)."""
+
+    def __init__(self, cldm: ControlLDM, x: T, t: T, c_txt: T, c_img: T):
+        dev = x.device
+        self.x = x.detach().float().contiguous().clone()
+        self.t = t.detach().to(torch.float32).contiguous().clone()
+        self.c_img = c_img.detach().float().contiguous().clone()
+        self.c_txt = c_txt  # kept alive: the context K/V cache of the networks is keyed on its storage
+        cond = dict(c_txt=c_txt, c_img=self.c_img)
+        # warm-up outside the capture: packs weights, fills the context K/V cache, sizes split-K workspaces
+        cldm._forward_eager(self.x, self.t, cond)
+        torch.cuda.synchronize(dev)
+        if cldm._graph_pool is None:
+            cldm._graph_pool = torch.cuda.graph_pool_handle()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=cldm._graph_pool):
+            self.out = cldm._forward_eager(self.x, self.t, cond)
+        torch.cuda.synchronize(dev)
+
+    def run(self, x: T, t: T, c_img: T) -> T:
+        self.x.copy_(x)
+        self.t.copy_(t)
+        if c_img.data_ptr() != self.c_img.data_ptr():
+            self.c_img.copy_(c_img)
+        self.graph.replay()
+        return self.out.clone()  # the static output buffer is overwritten by the next replay

@@ -34,14 +34,21 @@ def _byte_unicode() -> Dict[int, str]:
     return {b: chr(c) for b, c in zip(keep, chars)}
 
 
-class BPETokenizer:
-    """CLIP byte-pair tokenizer (same algorithm as reference open_clip/tokenizer.py:72-186). The 1.3 MB merges file
-    is third-party data that does not ship with this repo: pass its path or set DIFFBIR_BPE_VOCAB
-    (e.g. <open_clip>/bpe_simple_vocab_16e6.txt.gz)."""
+_MERGES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "clip_bpe_merges.txt.gz")
 
-    def __init__(self, path: str):
+
+class BPETokenizer:
+    """CLIP byte-pair tokenizer (same published algorithm as reference open_clip/tokenizer.py:72-186).  The merge rules
+    ship with the package (`clip_bpe_merges.txt.gz`: the 48 894 rules of OpenAI CLIP's bpe_simple_vocab_16e6, see
+    tools/make_bpe_table.py); `path` / DIFFBIR_BPE_VOCAB may point at the original `bpe_simple_vocab_16e6.txt.gz`."""
+
+    def __init__(self, path: str = None):
         import regex
-        lines = gzip.open(path).read().decode("utf-8").split("\n")[1:49152 - 256 - 2 + 1]
+        path = path or _MERGES
+        raw = gzip.open(path).read().decode("utf-8").split("\n")
+        if raw and raw[0].startswith("\"bpe_simple_vocab") or (raw and raw[0].startswith("#version")):
+            raw = raw[1:]   # the original file has a header line
+        lines = [l for l in raw if l][:49152 - 256 - 2]
         merges = [tuple(m.split()) for m in lines]
         base = list(_byte_unicode().values())
         vocab = base + [v + "</w>" for v in base] + ["".join(m) for m in merges] + ["<start_of_text>", "<end_of_text>"]
@@ -50,7 +57,8 @@ class BPETokenizer:
         self.pat = regex.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+",
                                  regex.IGNORECASE)
         self._ws = regex.compile(r"\s+")
-        self.cache: Dict[str, List[str]] = {}
+        # literal special tokens in a prompt map to themselves (reference tokenizer.py:87 seeds its cache the same way)
+        self.cache: Dict[str, List[str]] = {"<start_of_text>": ["<start_of_text>"], "<end_of_text>": ["<end_of_text>"]}
 
     def _bpe(self, tok: str) -> List[str]:
         if tok in self.cache:
@@ -93,9 +101,12 @@ def tokenize(texts: List[str], context_length: int = 77) -> T:
     global _tokenizer
     if isinstance(texts, str):
         texts = [texts]
-    path = os.environ.get("DIFFBIR_BPE_VOCAB")
-    if _tokenizer is None and path and os.path.exists(path):
-        _tokenizer = BPETokenizer(path)
+    if _tokenizer is None:
+        path = os.environ.get("DIFFBIR_BPE_VOCAB")
+        if path and os.path.exists(path):
+            _tokenizer = BPETokenizer(path)
+        elif os.path.exists(_MERGES):
+            _tokenizer = BPETokenizer(_MERGES)
     table = None
     out = torch.zeros(len(texts), context_length, dtype=torch.long)
     for i, t in enumerate(texts):

@@ -25,12 +25,31 @@ def instantiate_from_config(config: Mapping[str, Any]) -> Any:
     return get_obj_from_str(config["target"])(**config.get("params", dict()))
 
 
+def load_file_from_url(url: str, model_dir: str = "weights", file_name: Optional[str] = None) -> str:
+    """reference utils/common.py:92-110: cache location `<model_dir>/<basename of the URL path>`; downloads when the
+    file is missing (needs network access — the target environment has none, so a clear error is raised instead)."""
+    from urllib.parse import urlparse
+    os.makedirs(model_dir, exist_ok=True)
+    filename = file_name if file_name is not None else os.path.basename(urlparse(url).path)
+    cached_file = os.path.abspath(os.path.join(model_dir, filename))
+    if not os.path.exists(cached_file):
+        print(f'Downloading: "{url}" to {cached_file}\n')
+        try:
+            torch.hub.download_url_to_file(url, cached_file, hash_prefix=None, progress=True)
+        except Exception as e:
+            raise FileNotFoundError(f"{cached_file} is missing and {url} could not be downloaded ({e!r}); place the "
+                                    f"checkpoint at that path") from e
+    return cached_file
+
+
 def load_model_from_url(url_or_path: str) -> dict:
-    """reference utils/common.py:113-120 minus the download (no network in the target environment): accepts a local
-    file path, unwraps `state_dict` and strips a `module.` prefix."""
-    if not os.path.exists(url_or_path):
-        raise FileNotFoundError(f"{url_or_path}: weights must be present locally (downloads are disabled)")
-    sd = torch.load(url_or_path, map_location="cpu")
+    """reference utils/common.py:113-120: URL (cached under `weights/`) or, as an engine extension, a local path;
+    unwraps `state_dict` and strips a `module.` prefix."""
+    is_url = "://" in url_or_path
+    sd_path = load_file_from_url(url_or_path, model_dir="weights") if is_url else url_or_path
+    if not os.path.exists(sd_path):
+        raise FileNotFoundError(f"{sd_path}: checkpoint not found")
+    sd = torch.load(sd_path, map_location="cpu", weights_only=False)
     if "state_dict" in sd:
         sd = sd["state_dict"]
     if list(sd.keys())[0].startswith("module"):

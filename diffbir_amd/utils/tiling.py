@@ -81,17 +81,19 @@ class TiledModel:
         kimg = (c_img.data_ptr(), tuple(c_img.shape), c_img._version)
         if kimg not in self._cimg:  # condition latent is constant over the sampling steps: gather its tiles once
             self._cimg = {kimg: ops.tile_gather(c_img.float().contiguous(), coords, self.ts)}
-        ktxt = (c_txt.data_ptr(), tuple(c_txt.shape), c_txt._version)
+        n = Tn * B
+        step = max(B, (self.max_batch // B) * B)
+        # every chunk holds whole tiles, i.e. the same [B,77,D] context pattern: ONE repeated tensor serves all chunks
+        # (same storage -> one cross-attention K/V cache entry and one captured HIP graph per chunk size)
+        ktxt = (c_txt.data_ptr(), tuple(c_txt.shape), c_txt._version, step)
         if ktxt not in self._ctxt:
-            self._ctxt = {ktxt: c_txt.repeat(Tn, 1, 1).contiguous()}
+            self._ctxt = {ktxt: c_txt.repeat(min(step, n) // B, 1, 1).contiguous()}
         cimg_tiles, ctxt_rep = self._cimg[kimg], self._ctxt[ktxt]
         tiles = ops.tile_gather(x.float().contiguous(), coords, self.ts)
         t_rep = t.repeat(Tn)
-        n = Tn * B
-        step = max(B, (self.max_batch // B) * B)
         outs = []
         for i in range(0, n, step):
             j = min(n, i + step)
-            outs.append(self.forward(tiles[i:j], t_rep[i:j], {"c_txt": ctxt_rep[i:j], "c_img": cimg_tiles[i:j]}))
+            outs.append(self.forward(tiles[i:j], t_rep[i:j], {"c_txt": ctxt_rep[:j - i], "c_img": cimg_tiles[i:j]}))
         eps = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         return eps.contiguous()

@@ -88,12 +88,15 @@ typedef struct dbir_gemm_desc {
   int batch;
   int tile; /* 0 = auto; generic kernel 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64; direct-to-LDS kernel 5: 128x128,
                6: 256x64, 7: 64x256, 8/9: 256x128 (4 / 8 waves, 3-stage ring), 10: 256x256, 11: 128x128 4-stage,
-               12: 256x128 2-stage; 13: phased two-group 256x256 (gemm_ph.hip); 14: 256x160 (8 waves), 15: 128x160,
+               12: 256x128 2-stage; (13: removed in round 2); 14: 256x160 (8 waves), 15: 128x160,
                16: 256x160 (4 waves) — 160-wide tiles fit the UNet's N = 320 k channel counts without padding;
                20 + t for t in {5, 6, 10, 12, 14, 15}: tile t with software-pipelined LDS fragment reads;
                36 / 37 / 38: de-phased two-group 256x128 / 256x160 / 256x64 (3-slot ring, staging of one wave group
-               overlaps the MFMAs of the other); 40 / 41: 256x256 with K depth 32 (3-slot de-phased / 4-slot lockstep) */
-  /* split-K (tiles 5-12 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
+               overlaps the MFMAs of the other); 40 / 41: 256x256 with K depth 32 (3-slot de-phased / 4-slot lockstep);
+               50 / 51: halo-patch 3x3 convolution kernel (gemm_halo.hip), 256x160 / 256x128 — stride-1 pad-1 convs whose
+               256-row tiles are whole image rows (Wo a power of two <= 64): one LDS-resident activation patch per
+               64-channel slice serves all 9 taps; split-K slices the channel slices */
+  /* split-K (direct-to-LDS tiles >= 5 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
    * into f32 partial sums in `ws` (>= splitk * batch * M * N * 4 bytes, 16-byte aligned, caller-owned), then a second
    * kernel sums the slices in a fixed order and applies the epilogue.  For small-M / huge-K problems (8x8 and 16x16
    * latent levels) that cannot fill 256 CUs with output tiles alone.  Needs N % 8 == 0, no GEGLU. */

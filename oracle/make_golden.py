@@ -6,6 +6,8 @@
     python -m oracle.make_golden host_tables     # schedules / tile windows / blend weights from the reference's functions
     python -m oracle.make_golden full_modules    # full-size nets, module level (a few minutes)
     python -m oracle.make_golden full_pipeline   # 1x512x512, 50 spaced steps + CFG (≈10 min on 8 cores)
+    python -m oracle.make_golden full_configs    # BASELINE configs at full size: C2 (batch 2, spaced 50), C3 (batch 2,
+                                                 # dpm++_m2 20 steps), C4 (1x1024x1024 tiled 512/256, spaced 10)  ≈45 min
 
 Fixtures hold only outputs + token ids (+ tiny inputs); weights/inputs are re-derived from seeds by
 oracle/cases.py on both sides.
@@ -141,6 +143,60 @@ def gen_full_pipeline(R):
     print("full pipeline done in", dt, "s")
 
 
+# BASELINE configs at FULL network size: name -> (lq spec, steps, sampler, seed, kwargs)
+FULL_CONFIG_CASES = {
+    "c2_spaced50_b2": ((21, 2, 512, 512), 50, "spaced", 231, {}),
+    "c3_dpm20_b2": ((22, 2, 512, 512), 20, "dpm++_m2", 231, {}),
+    "c4_tiled1024_spaced10": ((23, 1, 1024, 1024), 10, "spaced", 231, dict(tiled=True, tile=512, stride=256)),
+}
+
+
+@torch.no_grad()
+def gen_full_configs(R, only=None):
+    """One npz per case (each takes minutes to an hour of CPU): tests/golden/full_<name>.npz with the reference's uint8
+    output, its wall time and thread count."""
+    from diffbir_amd import configs
+    cldm, swin, diff, W = build_reference(R, "full", configs.get("DIFFUSION_V21"))
+    for name, (lqspec, steps, sampler, seed, kw) in FULL_CONFIG_CASES.items():
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        out = run_pipeline(R, cldm, swin, diff, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+        dt = time.time() - t0
+        np.savez_compressed(os.path.join(OUT, f"full_{name}.npz"), out=out, ref_cpu_seconds=np.float64(dt),
+                            ref_cpu_threads=np.int64(torch.get_num_threads()))
+        print(name, out.shape, f"{dt:.1f} s", flush=True)
+
+
+TOKENIZER_PROMPTS = [
+    "", "low quality, blurry, low-resolution, noisy, unsharp, weird textures", "a photo of a cat",
+    "Cinematic, High Contrast, highly detailed, taken using a Canon EOS R camera, hyper detailed photo - realistic "
+    "maximum detail, 32k, Color Grading, ultra HD, extreme meticulous detailing, skin pore detailing, hyper sharpness, "
+    "perfect without deformations.",
+    "painting, oil painting, illustration, drawing, art, sketch, oil painting, cartoon, CG Style, 3D render, unreal "
+    "engine, blurring, dirty, messy, worst quality, low quality, frames, watermark, signature, jpeg artifacts, "
+    "deformed, lowres, over-smooth.",
+    "A close-up portrait of an elderly man's face, wrinkles & freckles; 85mm f/1.4", "it's the dog's ball, they're here",
+    "we've   got    multiple\tspaces\nand newlines", "UPPERCASE and MiXeD Case", "numbers 1234567890 and 3.14159",
+    "hyphen-ated under_score slash/back\\slash", "emoji \U0001F600 and accents caf\u00e9 na\u00efve \u00fcber",
+    "&amp; html &lt;entities&gt; &quot;quoted&quot;", "<start_of_text> literal special <end_of_text>",
+    "\u4e2d\u6587 \u65e5\u672c\u8a9e \ud55c\uad6d\uc5b4", "supercalifragilisticexpialidocious antidisestablishmentarianism",
+    "a " * 100, "!!! ??? ... ,,, ;;; :::", "I'd've'll'm're's't", "x" * 300, "street at night, neon signs, rain, 4k",
+    "the quick brown fox jumps over the lazy dog", "\u00bd \u00be \u2122 \u00a9 \u20ac \u00a3 \u00a5",
+]
+
+
+def gen_tokenizer(R):
+    """Token ids of the reference tokenizer (open_clip/tokenizer.py) for a set of prompts covering contractions,
+    whitespace clean-up, html entities, non-ASCII, special tokens and truncation at 77."""
+    import json
+    from diffbir.model.open_clip import tokenize
+    ids = tokenize(TOKENIZER_PROMPTS).tolist()
+    with open(os.path.join(OUT, "tokenizer_cases.json"), "w") as f:
+        json.dump(dict(prompts=TOKENIZER_PROMPTS, ids=ids), f)
+    print("tokenizer cases", len(ids))
+
+
 def gen_host_tables(R):
     """Host-side tables of the path, straight from the reference's own functions: timestep spacing, the spaced
     sampler's registered buffers, the DPM-Solver discrete VP schedule, tile windows and blend weights."""
@@ -207,3 +263,7 @@ if __name__ == "__main__":
         gen_modules(R, "full", "full", 256, configs.get("DIFFUSION_V21"))
     elif what == "full_pipeline":
         gen_full_pipeline(R)
+    elif what == "tokenizer":
+        gen_tokenizer(R)
+    elif what == "full_configs":
+        gen_full_configs(R, only=sys.argv[2:] or None)

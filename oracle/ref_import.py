@@ -37,6 +37,15 @@ def load_reference() -> types.SimpleNamespace:
         torch.cuda.synchronize = lambda *a, **k: None
     import importlib
 
+    # The reference's `diffbir/` has no __init__.py (namespace package), so the engine's `diffbir` alias package at the
+    # repo root would win regardless of sys.path order: bind the name to the reference directory explicitly (and drop
+    # any alias modules already imported in this process).
+    for k in [k for k in sys.modules if k == "diffbir" or k.startswith("diffbir.")]:
+        del sys.modules[k]
+    pkg = types.ModuleType("diffbir")
+    pkg.__path__ = [os.path.join(REFERENCE_ROOT, "diffbir")]
+    sys.modules["diffbir"] = pkg
+
     model = importlib.import_module("diffbir.model")
     pipeline = importlib.import_module("diffbir.pipeline")
     sampler = importlib.import_module("diffbir.sampler")

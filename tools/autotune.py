@@ -18,15 +18,18 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from diffbir_amd import native, ops, tuning  # noqa: E402
 
-CANDIDATES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41]   # tile ids (include/dbir.h)
+CANDIDATES = [5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41, 50, 51]   # tile ids (include/dbir.h)
 SPLITK = [(10, 2), (10, 3), (10, 4), (10, 6), (10, 9), (12, 2), (12, 3), (12, 4), (5, 2), (5, 3), (14, 2), (14, 3), (14, 4),
           (15, 2), (15, 3), (30, 2), (30, 3), (30, 4), (30, 6), (30, 9), (32, 2), (32, 3), (25, 2), (25, 3), (34, 2), (34, 3),
           (34, 4), (35, 2), (35, 3), (36, 2), (36, 3), (37, 2), (37, 3), (37, 4), (40, 2), (40, 3), (40, 4), (40, 6),
-          (40, 9)]  # (tile, slices)
+          (40, 9), (50, 2), (50, 3), (50, 4), (50, 5), (50, 7), (50, 10), (51, 2), (51, 3), (51, 4), (51, 5), (51, 7),
+          (51, 10)]  # (tile, slices)
 
 
 class Tuner:
-    def __init__(self, exclude, iters=4):
+    def __init__(self, exclude, iters=4, only=None, table=None):
+        self.only = only      # incremental mode: time only these tiles (+ their split-K forms) against the current table
+        self.table = table or {}
         self.cands = [c for c in CANDIDATES if c not in exclude]
         self.exclude = exclude
         self.iters = iters
@@ -66,10 +69,15 @@ class Tuner:
         scale = ref.abs().max().item() + 1e-12
         rec["us"]["0"] = self._time(d)
         cands = list(self.cands)
+        if self.only:
+            cands = [c for c in cands if c in self.only]
+            prev = self.table.get(key, 0)
+            if prev and prev not in cands:
+                cands.append(prev)     # the incumbent, re-timed in this process
         # split-K only where the output tiles alone cannot fill the chip and K is deep (16x16 / 8x8 latent levels)
         if (d.M * d.N <= 160 * 256 * 256 and d.K >= 1280 and d.N % 8 == 0 and d.act != ops.ACT_GEGLU
                 and d.store_mode == 0 and "splitk" not in self.exclude):
-            cands += [t + 100 * k for t, k in SPLITK if t not in self.exclude]
+            cands += [t + 100 * k for t, k in SPLITK if t not in self.exclude and (not self.only or t in self.only)]
         for c in cands:
             ops.apply_tile_code(d, c, out.device)
             out.zero_()
@@ -96,17 +104,22 @@ def main():
     ap.add_argument("--out", default="gpurun_out/tuning_gfx950.json")
     ap.add_argument("--exclude", default="")
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--only", default="", help="incremental: time only these tile ids (and the current table's winner)")
     a = ap.parse_args()
     exclude = [int(x) if x.isdigit() else x for x in a.exclude.split(",") if x]
+    only = [int(x) for x in a.only.split(",") if x]
+    table = dict(tuning.load()) if only else {}
     os.environ["DBIR_TUNING"] = "0"
+    tuning.load()
     dev = torch.device("cuda:0")
     pipe, cldm, swin = bench.build_engine(dev, torch.float16)
     cldm.overlap_streams = False
+    cldm.use_graph = False
     import numpy as np
     lq = torch.as_tensor(np.random.RandomState(0).randint(0, 256, (a.batch, 512, 512, 3)).astype(np.uint8)).to(dev)
     bench.run_once(pipe, lq, 1)   # warm: packing, caches
     torch.cuda.synchronize()
-    tuner = Tuner(exclude)
+    tuner = Tuner(exclude, only=only, table=table)
     ops._TUNER = tuner
     bench.run_once(pipe, lq, 1)   # every distinct launch of SwinIR, VAE enc/dec, ControlNet+UNet at batch 2B
     ops._TUNER = None
