@@ -1,79 +1,134 @@
 #!/usr/bin/env python
-"""bench.py — restored images/sec @512x512, 50-step SpacedSampler + CFG (BASELINE.json metric / configs[1]).
+"""bench.py — restored images/sec of the DiffBIR hot path on MI355X (BASELINE.json metric).
 
-One "step" = one full pass of the hot path over one batch: uint8 LQ batch [8,512,512,3] (resident in HBM) ->
-SwinIR -> VAE encode -> 50 spaced-DDPM steps over ControlNet+UNet with CFG 4.0 -> VAE decode -> wavelet colour
-fix -> uint8.  fp16 MFMA compute, synthetic seeded inputs, random-init weights of the real architecture
-(no checkpoints / datasets are reachable here).  N GPUs = N data-parallel replicas (one process per GPU, launched
-by torch.distributed.run), each restoring its own batch of 8 (weak scaling, no collective on the data path);
-timing = barrier + synchronize on both sides, max over ranks.
+Default (`--config c2`, BASELINE.json configs[1], the configuration the metric is quoted on): one "step" = one full pass
+of the hot path over one batch: uint8 LQ batch [8,512,512,3] (resident in HBM) -> SwinIR -> VAE encode -> 50 spaced-DDPM
+steps over ControlNet+UNet with CFG 4.0 -> VAE decode -> wavelet colour fix -> uint8.  fp16 MFMA compute, synthetic
+seeded inputs, random-init weights of the real architecture (no checkpoints / datasets are reachable here).
+
+Other BASELINE configs (each prints its own JSON line with its own roofline record):
+  --config c3   BFR, DPM-Solver++(2M) 20 steps + CFG, fp16, batch 4 per GPU (32 over 8 GPUs), data-parallel
+  --config c4   tiled sampling, 1x2048x2048, tile 512 / stride 256, 50 spaced steps; N > 1: tiles sharded (all-reduce)
+  --config c5   tiled sampling, 4096x4096, bf16, tiles sharded over the N GPUs (strong scaling: one image per step)
+
+N GPUs: one process per GPU over RCCL.  The driver launches `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N`; `python bench.py --gpus N` alone re-launches itself that way, and a WORLD_SIZE that disagrees with
+--gpus is an error.  c2 / c3 shard the batch (weak scaling, no collective on the data path); rank 0 creates the weights
+and ships them with the bucketed RCCL broadcast (`parallel.broadcast_state_dict`) before the timed region, and the
+restored uint8 batches are gathered to rank 0 (`parallel.gather_batch`) after it.  Timing = barrier + synchronize on
+both sides, max over ranks.
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
-  roofline     — dominant kernel family (implicit-GEMM MFMA kernel): algorithmic FLOPs / measured launch time
-  cpu_baseline — the oracle (CPU fp32 restatement of the reference, "port") timed on a bounded sample on rank 0.
+  roofline     — dominant kernel family (implicit-GEMM MFMA kernels): algorithmic FLOPs / measured launch time
+  cpu_baseline — the oracle (CPU fp32 restatement of the reference, "port") timed live on a bounded sample on rank 0,
+                 plus the unmodified reference's own measured time recorded when the golden vectors were generated.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOPS_PER_IMAGE = 111.2e12        # C2 image, duplicate VAE encode removed (algorithmic minimum)
+# SURVEY.md §8d algorithmic FLOPs (2*MAC; attention 4*Lq*Lk*d per head), per 512x512 image
+F_SWINIR, F_CLIP, F_VAE_ENC, F_VAE_DEC, F_EVAL = 0.181e12, 0.030e12, 1.117e12, 2.515e12, 1.073e12
 MFMA_PEAK = 2.5e15                # dense fp16/bf16, MI355X_MICROARCH.md
-BATCH = 8
 NEG = "low quality, blurry, low-resolution, noisy, unsharp, weird textures"
 
+CONFIGS = {
+    "c2": dict(batch=8, size=512, sampler="spaced", sampler_steps=50, dtype="fp16", tiled=False, scaling="weak",
+               desc="BSR pipeline, batch {b}x512x512 per GPU, {s}-step SpacedSampler + CFG=4.0, SwinIR+ControlLDM "
+                    "(SD-2.1 v-pred), {d}, data-parallel replicas"),
+    "c3": dict(batch=4, size=512, sampler="dpm++_m2", sampler_steps=20, dtype="fp16", tiled=False, scaling="weak",
+               desc="BFR pipeline, batch {b}x512x512 per GPU, DPM-Solver++(2M) {s} steps + CFG=4.0, {d}, data-parallel"),
+    "c4": dict(batch=1, size=2048, sampler="spaced", sampler_steps=50, dtype="fp16", tiled=True, scaling="strong",
+               desc="tiled sampling (mixture of diffusers), {b}x2048x2048, tile 512 / stride 256, {s}-step SpacedSampler "
+                    "+ CFG=4.0, {d}, tiles sharded over the GPUs"),
+    "c5": dict(batch=1, size=4096, sampler="spaced", sampler_steps=50, dtype="bf16", tiled=True, scaling="strong",
+               desc="tiled sampling, {b}x4096x4096, tile 512 / stride 256, {s}-step SpacedSampler + CFG=4.0, {d}, tiles "
+                    "sharded over the GPUs"),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2, help="timed pipeline passes (batches of 8 images)")
+    ap.add_argument("--steps", type=int, default=2, help="timed pipeline passes")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--sampler-steps", type=int, default=50)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per pass (default: the config's)")
+    ap.add_argument("--sampler-steps", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selftest", action="store_true",
-                    help="CPU / gloo dry run of the launch, barrier, max-over-ranks and JSON plumbing with a fake "
-                         "workload (tests/test_bench_plumbing_cpu.py); never a measurement")
-    return ap.parse_args()
+                    help="CPU / gloo dry run of the launch, barrier, broadcast, gather, max-over-ranks and JSON plumbing "
+                         "with a fake workload (tests/test_bench_plumbing_cpu.py); never a measurement")
+    a = ap.parse_args(argv)
+    c = CONFIGS[a.config]
+    a.batch = a.batch if a.batch is not None else c["batch"]
+    a.sampler_steps = a.sampler_steps if a.sampler_steps is not None else c["sampler_steps"]
+    a.dtype = a.dtype or c["dtype"]
+    return a
 
 
-def build_engine(device, dtype):
-    """Full-size DiffBIR v2.1 networks with random weights generated directly on the GPU."""
+def flops_per_image(cfg: dict, sampler_steps: int, batch: int) -> float:
+    """Algorithmic FLOPs of one restored image (duplicate VAE encode removed), fixed part + per-step part."""
+    px = (cfg["size"] / 512.0) ** 2
+    if cfg["tiled"]:
+        lat = cfg["size"] // 8
+        ntile = len(range(0, lat - 64 + 1, 32)) ** 2
+        per_step = 2 * ntile * F_EVAL
+    else:
+        per_step = 2 * F_EVAL
+    # SwinIR / VAE convs scale with the pixel count (the VAE mid-attention term grows faster; ignored here)
+    fixed = (F_SWINIR + F_VAE_ENC + F_VAE_DEC) * px + 2 * F_CLIP / max(batch, 1)
+    return fixed + sampler_steps * per_step
+
+
+def rand_state_dict(spec, device, gen):
+    import torch
+    sd = {}
+    for k, (shp, kind) in spec.items():
+        if kind == "buf":
+            continue
+        if kind == "w":
+            fan = 1
+            for s in shp[1:]:
+                fan *= s
+            sd[k] = torch.randn(shp, device=device, generator=gen) * (max(fan, 1) ** -0.5)
+        elif kind == "g":
+            sd[k] = 1.0 + 0.05 * torch.randn(shp, device=device, generator=gen)
+        else:
+            sd[k] = 0.02 * torch.randn(shp, device=device, generator=gen)
+    return sd
+
+
+def build_engine(device, dtype, ctx=None):
+    """Full-size DiffBIR v2.1 networks with random weights generated directly on the GPU.  With a multi-rank `ctx`
+    rank 0 generates them and every other rank receives them through the bucketed RCCL broadcast."""
     import torch
     from diffbir_amd import configs
     from diffbir_amd.model import ControlLDM, Diffusion, SwinIR
-    from diffbir_amd.model import specs
+    from diffbir_amd.parallel import broadcast_state_dict
     from diffbir_amd.pipeline import SwinIRPipeline
     g = torch.Generator(device=device).manual_seed(1234)
+    multi = ctx is not None and ctx.world > 1
 
-    def rand_sd(spec):
-        sd = {}
-        for k, (shp, kind) in spec.items():
-            if kind == "buf":
-                continue
-            if kind == "w":
-                fan = 1
-                for s in shp[1:]:
-                    fan *= s
-                sd[k] = torch.randn(shp, device=device, generator=g) * (max(fan, 1) ** -0.5)
-            elif kind == "g":
-                sd[k] = 1.0 + 0.05 * torch.randn(shp, device=device, generator=g)
-            else:
-                sd[k] = 0.02 * torch.randn(shp, device=device, generator=g)
-        return sd
+    def weights(mod):
+        sd = rand_state_dict(mod._spec, device, g) if (not multi or ctx.rank == 0) else None
+        return broadcast_state_dict(sd, mod._spec, ctx) if multi else sd
 
     cldm_cfg, swin_cfg = configs.get("FULL_CLDM"), configs.get("FULL_SWINIR")
     cldm = ControlLDM(**cldm_cfg)
-    for name, mod in (("unet", cldm.unet), ("controlnet", cldm.controlnet), ("vae", cldm.vae), ("clip", cldm.clip)):
-        mod.load_state_dict(rand_sd(mod._spec), strict=True)
+    for mod in (cldm.unet, cldm.controlnet, cldm.vae, cldm.clip):
+        mod.load_state_dict(weights(mod), strict=True)
     swin = SwinIR(**swin_cfg)
-    swin.load_state_dict(rand_sd(swin._spec), strict=True)
+    swin.load_state_dict(weights(swin), strict=True)
     cldm.to(device)
     swin.to(device)
     cldm.cast_dtype(dtype)
@@ -84,9 +139,9 @@ def build_engine(device, dtype):
     return SwinIRPipeline(swin, cldm, diff, None, str(device)), cldm, swin
 
 
-def run_once(pipe, lq, sampler_steps):
-    return pipe.run(lq, sampler_steps, 1.0, False, 512, 256, False, 256, False, 256, False, 512, 256, "", NEG, 4.0,
-                    "noise", "spaced", 0, False, 0, 0, 300, 1, 1, 1)
+def run_once(pipe, lq, sampler_steps, sampler="spaced", tiled=False):
+    return pipe.run(lq, sampler_steps, 1.0, False, 512, 256, False, 256, False, 256, tiled, 512, 256, "", NEG, 4.0,
+                    "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
 
 
 def measure_roofline(cldm, device, batch):
@@ -100,13 +155,14 @@ def measure_roofline(cldm, device, batch):
     t = torch.full((2 * batch,), 500.0, device=device)
     cond = dict(c_txt=c_txt, c_img=c_img)
     overlap, cldm.overlap_streams = cldm.overlap_streams, False   # per-launch durations are measured un-overlapped
+    graph, cldm.use_graph = cldm.use_graph, False
     cldm(x, t, cond)  # warm (context K/V cache, allocator)
     torch.cuda.synchronize()
-    prof = ops.start_profile()
+    ops.start_profile()
     cldm(x, t, cond)
     torch.cuda.synchronize()
     rec = ops.stop_profile()
-    cldm.overlap_streams = overlap
+    cldm.overlap_streams, cldm.use_graph = overlap, graph
     tot = {}
     for kind, flops, e0, e1, _tag, nbytes in rec:
         ms = e0.elapsed_time(e1)
@@ -116,20 +172,22 @@ def measure_roofline(cldm, device, batch):
         a[2] += 1
         a[3] += nbytes
     g = tot.get("gemm", [0.0, 1.0, 1, 0.0])
-    out = dict(bound="mfma", kernel="implicit-GEMM conv/linear family (gemm_glds_kernel / gemm_ph_kernel / gemm_kernel)",
+    out = dict(bound="mfma", kernel="implicit-GEMM conv/linear family (gemm_halo_kernel / gemm_glds_kernel / gemm_kernel)",
                achieved=g[0] / g[1] / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=g[0] / g[1] / MFMA_PEAK,
-               traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1],
+               traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1], eval_batch=2 * batch,
                avg_launch_us=g[1] / g[2] * 1e6, flops_per_launch=g[0] / g[2],
                algorithmic_bytes_per_launch=g[3] / g[2])
     # HBM bytes per GEMM launch from the rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/; FETCH_SIZE doubled
     # per the gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE), collected on the same network evaluation
-    pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if os.path.exists(pmc):
-        with open(pmc) as f:
-            t = json.load(f)
-        if t.get("gemm_bytes_per_eval"):
-            out["traffic"] = t["gemm_bytes_per_eval"] / g[2]   # HBM bytes per logical GEMM launch (incl. split-K slabs)
-        out["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc) and batch == 8:
+            with open(pmc) as f:
+                tr = json.load(f)
+            if tr.get("gemm_bytes_per_eval"):
+                out["traffic"] = tr["gemm_bytes_per_eval"] / g[2]   # HBM bytes per logical GEMM launch
+            out["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            break
     if "attention" in tot:
         a = tot["attention"]
         out["attention_kernel"] = dict(achieved=a[0] / a[1] / 1e12, frac=a[0] / a[1] / MFMA_PEAK, launches=a[2],
@@ -137,10 +195,12 @@ def measure_roofline(cldm, device, batch):
     return out
 
 
-def cpu_baseline(batch_unused):
-    """Oracle ("port": CPU fp32 restatement of the reference) on a bounded sample of the same workload: one 512x512
+def cpu_baseline():
+    """Oracle ("port": CPU fp32 restatement of the reference) on a bounded sample of the c2 workload: one 512x512
     image — SwinIR, VAE encode, ONE CFG sampler step (2 network evals), VAE decode — extrapolated to 50 steps
-    (per-step cost is constant)."""
+    (per-step cost is constant).  The unmodified reference cannot run on the GPU box (it is not shipped there); its own
+    wall time for the same image, measured when tests/golden/full_pipeline.npz was generated, is reported beside it."""
+    import numpy as np
     import torch
     from oracle import cases, nets
     cldm_cfg, swin_cfg = cases.get_cfgs("full")
@@ -167,47 +227,86 @@ def cpu_baseline(batch_unused):
         nets.vae_decode(W["vae"], cldm_cfg["vae_cfg"], xt, 0.18215)
         t_dec = time.time() - t0
     t_img = t_swin + t_enc + 50 * t_step + t_dec
-    return dict(value=1.0 / t_img, unit="images/sec", cores=cores, kind="port",
-                sample=f"1x512x512: SwinIR {t_swin:.1f}s + VAE-enc {t_enc:.1f}s + 1 of 50 CFG steps {t_step:.1f}s "
-                       f"(x50 extrapolated) + VAE-dec {t_dec:.1f}s => {t_img:.0f}s/image")
+    out = dict(value=1.0 / t_img, unit="images/sec", cores=cores, kind="port",
+               sample=f"1x512x512: SwinIR {t_swin:.1f}s + VAE-enc {t_enc:.1f}s + 1 of 50 CFG steps {t_step:.1f}s "
+                      f"(x50 extrapolated) + VAE-dec {t_dec:.1f}s => {t_img:.0f}s/image")
+    gp = os.path.join(ROOT, "tests", "golden", "full_pipeline.npz")
+    if os.path.exists(gp):
+        g = np.load(gp)
+        if "ref_cpu_seconds" in g:
+            sec, thr = float(g["ref_cpu_seconds"]), int(g["ref_cpu_threads"])
+            out["reference_recorded"] = dict(
+                value=1.0 / sec, unit="images/sec", cores=thr, kind="reference",
+                sample=f"unmodified reference SwinIRPipeline.run, 1x512x512, 50 spaced steps + CFG, CPU fp32: {sec:.1f} s "
+                       f"on {thr} threads of the build container (recorded by oracle/make_golden.py, not re-timed here)")
+    return out
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: re-run under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    cfg = CONFIGS[args.config]
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                 f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` without a launcher)")
     import numpy as np
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from diffbir_amd import parallel
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    extra = {}
     if args.selftest:
+        ctx = parallel.init_distributed("gloo", torch.device("cpu"))
         device, sync = torch.device("cpu"), (lambda: None)
-        if world > 1:
-            dist.init_process_group("gloo")
         dtype = torch.float16
-        pipe = cldm = swin = None
-        lq_dev = None
+        pipe = cldm = None
+        if world > 1:   # the weight broadcast with a small spec
+            spec = {"a.weight": ((64, 32), "w"), "a.bias": ((64,), "b"), "n.weight": ((7,), "g")}
+            sd = rand_state_dict(spec, device, torch.Generator().manual_seed(5)) if rank == 0 else None
+            got = parallel.broadcast_state_dict(sd, spec, ctx, bucket_bytes=4096)
+            chk = torch.stack([v.double().sum() for v in got.values()]).sum().reshape(1)
+            lo_hi = [chk.clone() for _ in range(world)]
+            dist.all_gather(lo_hi, chk)
+            assert all(torch.equal(v, lo_hi[0]) for v in lo_hi), "broadcast_state_dict: ranks disagree"
+            extra["broadcast_checked"] = True
 
         def run_step():
             time.sleep(0.02 * (1 + rank))  # ranks differ: the reported time must be the slowest rank's
-            return np.zeros((args.batch, 512, 512, 3), dtype=np.uint8)
+            return np.full((args.batch, 64, 64, 3), rank, dtype=np.uint8)
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-        torch.cuda.set_device(local)
-        device, sync = torch.device("cuda", local), torch.cuda.synchronize
-        if world > 1:
-            dist.init_process_group("nccl", device_id=device)
+        ctx = parallel.init_distributed("nccl")
+        device, sync = ctx.device, torch.cuda.synchronize
         from diffbir_amd import native
         native.lib()
         dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-        pipe, cldm, swin = build_engine(device, dtype)
-        rs = np.random.RandomState(100 + rank)
-        lq = rs.randint(0, 256, (args.batch, 512, 512, 3)).astype(np.uint8)
+        pipe, cldm, swin = build_engine(device, dtype, ctx)
+        if world > 1:
+            extra["weights"] = "generated on rank 0, shipped by parallel.broadcast_state_dict (RCCL, 256 MB buckets)"
+        rs = np.random.RandomState(100 + (0 if cfg["tiled"] else rank))
+        lq = rs.randint(0, 256, (args.batch, cfg["size"], cfg["size"], 3)).astype(np.uint8)
         lq_dev = torch.as_tensor(lq).to(device)          # inputs resident in HBM before the timed region
-        torch.manual_seed(231 + rank)
+        if cfg["tiled"]:
+            parallel.enable_tile_sharding(pipe, ctx, seed=231)   # same noise on every rank, tiles rank::world
+        else:
+            torch.manual_seed(231 + rank)
 
         def run_step():
-            return run_once(pipe, lq_dev, args.sampler_steps)
+            return run_once(pipe, lq_dev, args.sampler_steps, cfg["sampler"], cfg["tiled"])
 
     def barrier():
         sync()
@@ -227,29 +326,44 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert out.shape == (args.batch, 512, 512, 3) and out.dtype == np.uint8
-    images = args.batch * args.steps * world
+    assert out.dtype == np.uint8 and out.shape[0] == args.batch
+    sharded_batch = not cfg["tiled"]
+    if world > 1 and sharded_batch:   # outside the timed region: the restored slices travel to rank 0 over RCCL
+        full = parallel.gather_batch(out, args.batch * world, ctx)
+        if rank == 0:
+            assert full.shape == (args.batch * world,) + out.shape[1:], full.shape
+            if args.selftest:
+                assert all(int(full[r * args.batch, 0, 0, 0]) == r for r in range(world)), "gather_batch order"
+            extra["gathered_batch"] = list(full.shape)
+    images = args.batch * args.steps * (world if sharded_batch else 1)
     value = images / dt
+    fpi = flops_per_image(cfg, args.sampler_steps, args.batch)
     res = {
-        "metric": "restored images/sec @512x512, 50-step SpacedSampler+CFG", "value": value, "unit": "images/sec",
+        "metric": "restored images/sec @512x512, 50-step SpacedSampler+CFG" if args.config == "c2" else
+                  f"restored images/sec ({args.config})",
+        "value": value, "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
+        "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
+        "dtype": "f16" if dtype == torch.float16 else "bf16",
         "data": "synthetic (seeded uint8 noise images, random-init weights of the real architecture)",
-        "config": {"workload": f"BSR pipeline, batch {args.batch}x512x512 per GPU, {args.sampler_steps}-step "
-                               "SpacedSampler + CFG=4.0, SwinIR+ControlLDM (SD-2.1 v-pred), fp16, data-parallel replicas",
-                   "global_batch": args.batch * world, "sampler_steps": args.sampler_steps, "parallelism": f"dp{world}"},
-        "mfma_frac_end_to_end": value * FLOPS_PER_IMAGE * (args.sampler_steps / 50.0) / (world * MFMA_PEAK),
+        "config": {"workload": cfg["desc"].format(b=args.batch, s=args.sampler_steps, d=args.dtype), "name": args.config,
+                   "global_batch": args.batch * (world if sharded_batch else 1), "sampler_steps": args.sampler_steps,
+                   "parallelism": (f"dp{world}" if sharded_batch else f"tile-shard{world}")},
+        "flops_per_image": fpi,
+        "mfma_frac_end_to_end": value * fpi / (world * MFMA_PEAK),
+        "vs_baseline_note": "BASELINE.json `published` is empty: the reference publishes no throughput numbers",
     }
+    res.update(extra)
     if args.selftest:
         res["data"] = "SELFTEST (fake workload, CPU/gloo) - not a measurement"
     if rank == 0 and not args.no_roofline and not args.selftest:
-        res["roofline"] = measure_roofline(cldm, device, args.batch)
+        res["roofline"] = measure_roofline(cldm, device, 16 if cfg["tiled"] else args.batch)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.selftest:
-        del pipe, cldm, swin
+        del pipe, cldm
         torch.cuda.empty_cache()
-        res["cpu_baseline"] = cpu_baseline(args.batch)
+        res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

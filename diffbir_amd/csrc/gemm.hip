@@ -303,7 +303,7 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 59 && tile != 13, "dbir_gemm: bad tile %d", tile);
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 69 && tile != 13, "dbir_gemm: bad tile %d", tile);
   if (tile == 0 || tile >= 5) {
     const bool ok = dbir_gemm_glds_eligible(d);
     DBIR_CHECK_ARG(ok || tile == 0, "dbir_gemm: tile %d (direct-to-LDS kernel) needs K/Cin %% 64 == 0, 16-byte aligned "

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
   }
 }
 
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0, int BKT = 64>
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0, int BKT = 64, int WPS = 0>
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int RPP_ = 64 * WM * WN / (BKT / 8), BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
@@ -518,7 +518,8 @@ int launch2(G2Params& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   constexpr int blocks_per_cu = (160 * 1024) / lds;
   constexpr int waves = WM * WN * (blocks_per_cu > 2 ? 2 : blocks_per_cu);
-  constexpr int MINW = waves >= 8 ? 2 : 1;
+  // WPS > 0: explicit waves per SIMD (register budget 512 / WPS) for variants meant to run several blocks per CU
+  constexpr int MINW = WPS > 0 ? WPS : (waves >= 8 ? 2 : 1);
   auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE, DEPH, BKT>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -592,6 +593,10 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
     // K depth 32: the 256x256 tile fits a 3-slot ring (96 KB) -> de-phased / 4-slot lockstep variants
     case 40: return launch2<T, 2, 4, 4, 2, 3, 1, 1, 32>(p, s);  // 256x256 de-phased
     case 41: return launch2<T, 2, 4, 4, 2, 4, 1, 0, 32>(p, s);  // 256x256 lockstep, 4-slot ring
+    // K depth 32, <= 80 KB of LDS and <= 128 VGPRs: TWO (three) independent blocks per CU, so one block's prologue /
+    // epilogue (HBM-bound, GELU-heavy for GEGLU) overlaps another block's K loop without any in-kernel scheduling
+    case 44: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 32, 4>(p, s);  // 256x128, 8 waves (64x64 each), 3-slot ring, 72 KB
+    case 45: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 32, 3>(p, s);  // 128x128, 4 waves, 3-slot ring, 48 KB: 3 blocks / CU
   }
   dbir_set_error("dbir_gemm: bad glds tile %d", tile);
   return DBIR_ERR_ARG;

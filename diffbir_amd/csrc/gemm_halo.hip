@@ -54,7 +54,11 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int WM, int WN, int MI, int NJ, int PMAX>
+// ABL (diagnostic ablations, tiles 60-63, timing only — results are wrong by construction): 1 = no epilogue, 2 = no
+// MFMAs, 3 = no steady-state staging, 4 = no fragment reads.
+// LS = 1: lockstep schedule with cross-tile fragment prefetch (see the LS block in the body) instead of the two
+// de-phased wave groups.
+template <typename T, int WM, int WN, int MI, int NJ, int PMAX, int ABL = 0, int LS = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_halo_kernel(const HParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NT = 64 * WM * WN;
@@ -194,6 +198,115 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_halo_kernel(const HParam
   __builtin_amdgcn_raw_ptr_buffer_load_lds(a_srd, (lptr_t)(smem + (BUF) * PBUF_BYTES + (PIECE) * PASS_BYTES + wave * 1024), \
                                            16, a_voff[PIECE], (C) * 128, 0, 0)
 
+  if constexpr (LS) {
+    // ---- LS schedule: all waves in lockstep, ONE barrier per K tile, no drain in steady state -----------------------
+    // Ring: tile kt in slot kt % 3.  Iteration kt:  wait (this wave's loads of tile kt+1 landed; only a patch piece issued
+    // in the previous iteration may stay in flight) -> barrier (everyone's share landed; everyone is done with slot
+    // (kt-1) % 3) -> issue W(kt+2) into that slot (+ a piece of the next slice's patch) -> 4 k-steps of MFMAs, the
+    // fragment reads running one k-step ahead ACROSS the tile boundary: the last k-step's MFMAs cover the reads of tile
+    // kt+1's first fragments, so after the next barrier the matrix pipe starts at once (the de-phased schedule pays a
+    // barrier + ds_read latency bubble at the head of every multiply section: profiles/r2_halo_ablation.txt).
+    //   RAW W: tile kt+1 was issued in iteration kt-1 and is waited for before barrier kt, its first read follows it.
+    //   RAW patch: pieces go out in taps 0..NPASS-1 <= 5, older than W(c+1, 0) (issued in tap 7) in the in-order queue.
+    //   WAR: slot (kt-1) % 3 / patch buffer (c+1) & 1 were last read in iteration kt-1 / (c-1, 8), before barrier kt.
+    const int nk = nsl * 9;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) STAGE_P(c0, i, 0);
+    STAGE_W(c0, 0, 0);
+    if (nk > 1) STAGE_W(c0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    typename T::vec8 xf[2][MI], wf[2][NJ];
+    int arow[MI], akey[MI];
+    const char* bbase = smem;
+#define TAP_ADDR(TAP, PBUF)                                                     \
+  do {                                                                          \
+    const int ky_ = (TAP) / 3, kx_ = (TAP) % 3;                                 \
+    const int toff_ = (ky_ - 1) * Wo + (kx_ - 1);                               \
+    const int pbase_ = (PBUF) * PBUF_BYTES;                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) {                         \
+      int pp_ = ppc[i_] + toff_;                                                \
+      if (kx_ == 0) pp_ = xl[i_] ? PMAX : pp_;                                  \
+      if (kx_ == 2) pp_ = xr[i_] ? PMAX : pp_;                                  \
+      arow[i_] = pbase_ + (pp_ << 7);                                           \
+      akey[i_] = (pp_ << 3) & 0x70;                                             \
+    }                                                                           \
+  } while (0)
+#define LOAD_FRAGS_L(KS, SET)                                                                                 \
+  do {                                                                                                        \
+    const int co_ = ((2 * (KS) + hi) ^ sw) * 16;                                                              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) wf[SET][j] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(bbase + b_frag + j * FSTR + co_);                          \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) xf[SET][i] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(smem + arow[i] + ((((KS) * 32) + hik) ^ akey[i]));          \
+  } while (0)
+    TAP_ADDR(0, 0);
+    LOAD_FRAGS_L(0, 0);
+    int s_slot = 2, c_slot = 0;
+    bool piece_prev = false;
+    for (int cc = 0; cc < nsl; ++cc) {
+      const int c = c0 + cc;
+      const int pbuf = cc & 1;
+      const bool next_slice = cc + 1 < nsl;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const bool more1 = next_slice || t < 8;          // a tile kt+1 exists
+        const bool more2 = next_slice || t < 7;          // a tile kt+2 exists
+        if (more1) {
+          if (piece_prev)
+            wait_vm<1>();
+          else
+            wait_vm<0>();
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_barrier" ::: "memory");
+        }
+        if (more2 && ABL != 3) {
+          if (t < 7)
+            STAGE_W(c, t + 2, s_slot);
+          else
+            STAGE_W(c + 1, t - 7, s_slot);
+          s_slot = (s_slot + 1 == STAGES) ? 0 : s_slot + 1;
+        }
+        piece_prev = false;
+        if (t < NPASS && ABL != 3) {
+          if (next_slice) {
+            STAGE_P(c + 1, (t < NPASS ? t : 0), pbuf ^ 1);
+            piece_prev = true;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks < 3) {
+            if (ABL != 4) LOAD_FRAGS_L(ks + 1, (ks + 1) & 1);
+          } else if (more1) {
+            // fragments of the NEXT tile's first k-step (its slot / tap / patch buffer)
+            c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
+            bbase = smem + c_slot * B_BYTES;
+            if (t < 8)
+              TAP_ADDR(t + 1, pbuf);
+            else
+              TAP_ADDR(0, pbuf ^ 1);
+            if (ABL != 4) LOAD_FRAGS_L(0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (ABL == 2) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(wf[ks & 1][j]));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(xf[ks & 1][i]));
+          } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[ks & 1][j], xf[ks & 1][i], acc[i][j]);  // D[n][m]
+          }
+        }
+      }
+    }
+#undef TAP_ADDR
+#undef LOAD_FRAGS_L
+  } else {
   // ---- prologue: whole patch of the first slice + weight tile (c0, 0) ----
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) STAGE_P(c0, i, 0);
@@ -211,15 +324,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_halo_kernel(const HParam
     for (int t = 0; t < 9; ++t) {
       const bool more = next_slice || t < 8;
       // ---- stage: weight tile of the next K tile (+ one piece of the next slice's patch) ----
-      if (more) {
+      if (more && ABL != 3) {
         if (t < 8)
           STAGE_W(c, t + 1, s_slot);
         else
           STAGE_W(c + 1, 0, s_slot);
         s_slot = (s_slot + 1 == STAGES) ? 0 : s_slot + 1;
       }
-      const bool piece = (t >= 1 && t - 1 < NPASS) && next_slice;
-      if (t >= 1 && t - 1 < NPASS) {
+      const bool piece = (t >= 1 && t - 1 < NPASS) && next_slice && ABL != 3;
+      if (t >= 1 && t - 1 < NPASS && ABL != 3) {
         if (next_slice) STAGE_P(c + 1, (t - 1 < NPASS ? t - 1 : 0), pbuf ^ 1);
       }
       if (grp == 0) {
@@ -257,15 +370,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_halo_kernel(const HParam
     _Pragma("unroll") for (int i = 0; i < MI; ++i) xf[SET][i] =                                               \
         *reinterpret_cast<const typename T::vec8*>(smem + arow[i] + ((((KS) * 32) + hik) ^ akey[i]));          \
   } while (0)
-        LOAD_FRAGS_H(0, 0);
+        if (ABL != 4 || (cc == 0 && t == 0)) LOAD_FRAGS_H(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          if (ks < 3) LOAD_FRAGS_H(ks + 1, (ks + 1) & 1);
+          if (ks < 3 && (ABL != 4 || (cc == 0 && t == 0))) LOAD_FRAGS_H(ks + 1, (ks + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (ABL == 2) {
 #pragma unroll
-          for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(wf[ks & 1][j]));
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[ks & 1][j], xf[ks & 1][i], acc[i][j]);  // D[n][m]
+            for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(xf[ks & 1][i]));
+          } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[ks & 1][j], xf[ks & 1][i], acc[i][j]);  // D[n][m]
+          }
         }
 #undef LOAD_FRAGS_H
       }
@@ -275,9 +395,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_halo_kernel(const HParam
     }
   }
   if (grp == 0) asm volatile("s_barrier" ::: "memory");  // pairs group 1's extra barrier
+  }  // de-phased schedule
 #undef STAGE_W
 #undef STAGE_P
 
+  if constexpr (ABL == 1) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   {
     EpiParams ep;
     ep.vec_bias = p.vec_bias;
@@ -331,7 +459,7 @@ bool halo_geometry(const dbir_gemm_desc& d, int BM, int PMAX, HParams& p) {
 // split-K second pass shared with gemm_glds.hip
 int dbir_splitk_reduce_launch(const dbir_gemm_desc& d, int splitk, float* ws, hipStream_t s);
 
-template <typename T, int WM, int WN, int MI, int NJ, int PMAX>
+template <typename T, int WM, int WN, int MI, int NJ, int PMAX, int ABL = 0, int LS = 0>
 static int launch_halo(HParams& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int ring = 2 * (PMAX * 128 + 256) + 3 * BN * 128, epi = BM * (BN + 8) * 2;
@@ -362,7 +490,7 @@ static int launch_halo(HParams& p, hipStream_t s) {
   }
   p.mtiles = cdiv(dd.M, BM);
   p.ntiles = cdiv(dd.N, BN);
-  auto kern = &gemm_halo_kernel<T, WM, WN, MI, NJ, PMAX>;
+  auto kern = &gemm_halo_kernel<T, WM, WN, MI, NJ, PMAX, ABL, LS>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -396,6 +524,19 @@ int dbir_gemm_halo(const dbir_gemm_desc& dd, int tile, hipStream_t s) {
       return f16 ? launch_halo<F16, 8, 1, 1, 5, 384>(p, s) : launch_halo<BF16, 8, 1, 1, 5, 384>(p, s);
     case 51:  // 256x128, 8 waves (64x64 each)
       return f16 ? launch_halo<F16, 4, 2, 2, 2, 384>(p, s) : launch_halo<BF16, 4, 2, 2, 2, 384>(p, s);
+    case 52:  // 256x160, lockstep schedule with cross-tile fragment prefetch
+      return f16 ? launch_halo<F16, 8, 1, 1, 5, 384, 0, 1>(p, s) : launch_halo<BF16, 8, 1, 1, 5, 384, 0, 1>(p, s);
+    case 53:  // 256x128, lockstep schedule
+      return f16 ? launch_halo<F16, 4, 2, 2, 2, 384, 0, 1>(p, s) : launch_halo<BF16, 4, 2, 2, 2, 384, 0, 1>(p, s);
+    case 64: return launch_halo<F16, 8, 1, 1, 5, 384, 1, 1>(p, s);   // ablations of tile 52
+    case 65: return launch_halo<F16, 8, 1, 1, 5, 384, 2, 1>(p, s);
+    case 66: return launch_halo<F16, 8, 1, 1, 5, 384, 3, 1>(p, s);
+    case 67: return launch_halo<F16, 8, 1, 1, 5, 384, 4, 1>(p, s);
+    // diagnostic ablations of tile 50 (f16 only; outputs are meaningless): tools/halo_ablate.py
+    case 60: return launch_halo<F16, 8, 1, 1, 5, 384, 1>(p, s);
+    case 61: return launch_halo<F16, 8, 1, 1, 5, 384, 2>(p, s);
+    case 62: return launch_halo<F16, 8, 1, 1, 5, 384, 3>(p, s);
+    case 63: return launch_halo<F16, 8, 1, 1, 5, 384, 4>(p, s);
   }
   dbir_set_error("dbir_gemm: bad halo tile %d", tile);
   return DBIR_ERR_ARG;

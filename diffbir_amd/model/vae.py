@@ -3,8 +3,9 @@
 NHWC 16-bit; every conv is a fused implicit-GEMM launch, GroupNorm(eps 1e-6)+swish is one fused kernel chain,
 the (0,1,0,1)-padded stride-2 downsample (vae.py:50-54) and the nearest-x2 upsample (vae.py:34) are address math
 inside the conv gather.  The mid-block attention is single-head with d = C = 512: it runs as two batched MFMA
-GEMMs (Q K^T, P V) around a row-softmax kernel; with 288 GB of HBM the [L, L] score matrix is simply
-materialised (L = 4096 at 512x512).
+GEMMs (Q K^T, P V) around a row-softmax kernel, over QUERY CHUNKS of at most `ATTN_CHUNK_BYTES` of scores: exact
+attention (every query row sees all keys), but never an [L, L] matrix — L = 4096 at 512x512 is one chunk, L = 262144
+at 4096x4096 (137 GB of scores if materialised) runs in 4 GB pieces.
 """
 from typing import Optional
 
@@ -15,6 +16,9 @@ from .base import NativeModule
 from .specs import vae_spec
 
 T = torch.Tensor
+
+
+ATTN_CHUNK_BYTES = 4 << 30   # upper bound of the per-chunk score buffer [B, Lq_chunk, L] (16-bit)
 
 
 class _VRes:
@@ -109,11 +113,15 @@ class AutoencoderKL(NativeModule):
         vt = torch.zeros((B, C, Lp), dtype=x.dtype, device=x.device) if Lp != L else \
             torch.empty((B, C, Lp), dtype=x.dtype, device=x.device)
         ops.linear_t(hn, a["v"], L, vt)
-        s = torch.empty((B, L, Lp), dtype=x.dtype, device=x.device)
-        ops.bmm_nt(qk[..., :C], qk[..., C:], s[..., :L] if Lp != L else s, out_scale=float(C) ** -0.5)
-        ops.softmax_rows_(s, L)
         o = torch.empty((B, L, C), dtype=x.dtype, device=x.device)
-        ops.bmm_nt(s, vt, o)
+        rows = max(64, min(L, (ATTN_CHUNK_BYTES // (2 * B * Lp)) // 64 * 64))   # query rows per chunk
+        s = torch.empty((B, rows, Lp), dtype=x.dtype, device=x.device)
+        for q0 in range(0, L, rows):
+            n = min(rows, L - q0)
+            sc = s if n == rows else s.reshape(-1)[: B * n * Lp].view(B, n, Lp)   # dense [B, n, Lp] in the same memory
+            ops.bmm_nt(qk[:, q0:q0 + n, :C], qk[..., C:], sc[..., :L] if Lp != L else sc, out_scale=float(C) ** -0.5)
+            ops.softmax_rows_(sc, L)
+            ops.bmm_nt(sc, vt, o[:, q0:q0 + n])
         return ops.linear(o.reshape(B, H, W, C), a["proj"], residual=x)
 
     # ------------------------------------------------------------------ API

@@ -34,6 +34,7 @@ class DistContext:
     world: int = 1
     device: torch.device = torch.device("cpu")
     group: Optional[object] = None
+    _noise: Optional[Callable] = None   # persistent shared-seed noise stream of run_data_parallel
 
     @property
     def is_main(self) -> bool:
@@ -153,10 +154,39 @@ def gather_batch(local: np.ndarray, batch: int, ctx: DistContext, dst: int = 0) 
     return np.concatenate(parts, axis=0)
 
 
-def enable_tile_sharding(pipe, ctx: DistContext) -> None:
-    """Tiled sampling evaluates tiles rank::world on this rank and all-reduces the partial sums."""
-    pipe.tile_shard = (ctx.rank, ctx.world) if ctx.world > 1 else None
-    pipe.tile_all_reduce = all_reduce_sum(ctx) if ctx.world > 1 else None
+def enable_tile_sharding(pipe, ctx: DistContext, seed: Optional[int] = 231, check_every: int = 0) -> None:
+    """Tiled sampling evaluates tiles rank::world on this rank and all-reduces the partial sums.
+
+    Every rank performs the sampler update redundantly, so every rank MUST draw the same x_T and per-step noise: unless
+    the caller already installed a shared noise source (`pipe.randn`), an identically seeded device generator is
+    installed here (`seed=None` leaves the pipeline alone — then the caller is responsible).  `check_every = n > 0`
+    additionally all-reduces a checksum of the blended prediction every n evaluations and raises if the ranks' inputs
+    have diverged (debug aid: one extra 8-byte all-reduce)."""
+    if ctx.world <= 1:
+        pipe.tile_shard, pipe.tile_all_reduce = None, None
+        return
+    pipe.tile_shard = (ctx.rank, ctx.world)
+    reduce = all_reduce_sum(ctx)
+    if check_every > 0:
+        state = {"n": 0}
+
+        def checked(t: torch.Tensor) -> torch.Tensor:
+            t = reduce(t)
+            state["n"] += 1
+            if state["n"] % check_every == 0:
+                s = t.double().sum().reshape(1)
+                lo, hi = s.clone(), s.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=ctx.group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=ctx.group)
+                if not torch.equal(lo, hi):
+                    raise RuntimeError("tile sharding: ranks hold different reduced tensors — were x_T / the step noise "
+                                       "drawn from differently seeded generators?")
+            return t
+        pipe.tile_all_reduce = checked
+    else:
+        pipe.tile_all_reduce = reduce
+    if seed is not None and getattr(pipe, "randn", None) is None:
+        pipe.randn = ShardedNoise.seeded(seed, ctx.device)
 
 
 def run_data_parallel(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise: Optional[Callable] = None,
@@ -169,7 +199,13 @@ def run_data_parallel(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, n
     this rank's slice."""
     B = lq.shape[0]
     lo, hi = shard_range(B, ctx.rank, ctx.world)
-    base = noise if noise is not None else ShardedNoise.seeded(231, ctx.device)
+    if noise is None:
+        # ONE generator per context, seeded once: successive batches keep drawing from the same stream (the reference
+        # seeds once per process, inference.py:293), instead of replaying the same noise for every batch
+        if getattr(ctx, "_noise", None) is None:
+            ctx._noise = ShardedNoise.seeded(231, ctx.device)
+        noise = ctx._noise
+    base = noise
     prev = pipe.randn
     pipe.randn = ShardedNoise(base, B, lo, hi) if ctx.world > 1 else base
     try:

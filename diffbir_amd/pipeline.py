@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .sampler import DPMSolverSampler, SpacedSampler
+from .sampler import DDIMSampler, DPMSolverSampler, EDMSampler, SpacedSampler
 from .utils.common import make_tiled_fn, wavelet_reconstruction
 
 
@@ -54,6 +54,8 @@ class Pipeline:
         # engine extension (diffbir_amd.parallel): shard the tiles of tiled sampling over (rank, world)
         self.tile_shard: Optional[Tuple[int, int]] = None
         self.tile_all_reduce: Optional[Callable] = None
+        # engine extension: Brownian-motion factory handed to the EDM SDE solvers (sampler/edm_sampler.py BrownianPath)
+        self.brownian: Optional[Callable] = None
 
     def _randn(self, shape) -> torch.Tensor:
         if self.randn is not None:
@@ -112,14 +114,18 @@ class Pipeline:
         betas, parameterization = self.diffusion.betas, self.diffusion.parameterization
         if sampler_type == "spaced":
             sampler = SpacedSampler(betas, parameterization, rescale_cfg)
+        elif sampler_type == "ddim":
+            sampler = DDIMSampler(betas, parameterization, rescale_cfg, eta=0)
         elif sampler_type.startswith("dpm"):
             sampler = DPMSolverSampler(betas, parameterization, rescale_cfg, sampler_type)
-        elif sampler_type == "ddim" or sampler_type.startswith("edm"):
-            raise NotImplementedError(f"{sampler_type}: DDIM / EDM samplers are outside this engine's hot-path scope "
-                                      "(SURVEY.md §8f N2); use 'spaced' or 'dpm++_m2'")
+        elif sampler_type.startswith("edm"):
+            sampler = EDMSampler(betas, parameterization, rescale_cfg, sampler_type, s_churn, s_tmin, s_tmax, s_noise,
+                                 eta, order)
         else:
             raise NotImplementedError(sampler_type)
         sampler.randn = self.randn
+        if self.brownian is not None and hasattr(sampler, "brownian"):
+            sampler.brownian = self.brownian
         sampler.tile_shard, sampler.tile_all_reduce = self.tile_shard, self.tile_all_reduce
         try:
             z = sampler.sample(model=self.cldm, device=self.device, steps=steps, x_size=(bs, 4, h2, w2), cond=cond,

@@ -197,6 +197,95 @@ def gen_tokenizer(R):
     print("tokenizer cases", len(ids))
 
 
+# DDIM + EDM / k-diffusion samplers on the tiny config: name -> (sampler, steps, extra run args)
+SAMPLER_CASES = {
+    "ddim8": ("ddim", 8, {}),
+    "ddim5_rescale": ("ddim", 5, dict(rescale_cfg=True, cfg=3.0)),
+    "edm_euler": ("edm_euler", 6, {}),
+    "edm_euler_churn": ("edm_euler", 6, dict(s_churn=4.0, s_tmin=0.05, s_tmax=50.0, s_noise=1.003)),
+    "edm_euler_a": ("edm_euler_a", 6, {}),
+    "edm_heun": ("edm_heun", 5, {}),
+    "edm_dpm_2": ("edm_dpm_2", 5, {}),
+    "edm_dpm_2_a": ("edm_dpm_2_a", 5, {}),
+    "edm_lms": ("edm_lms", 7, dict(order=3)),
+    "edm_dpm++_2s_a": ("edm_dpm++_2s_a", 5, {}),
+    "edm_dpm++_2m": ("edm_dpm++_2m", 8, {}),
+    # SDE solvers: torchsde is not installed here, so k_diffusion.BrownianTreeNoiseSampler is replaced ON BOTH SIDES by
+    # a stand-in that returns a fresh N(0, 1) draw per call (solver arithmetic under test, not the Brownian tree)
+    "edm_dpm++_sde": ("edm_dpm++_sde", 5, {}),
+    "edm_dpm++_2m_sde": ("edm_dpm++_2m_sde", 8, {}),
+    "edm_dpm++_3m_sde": ("edm_dpm++_3m_sde", 10, {}),
+    "edm_dpm++_3m_sde_eps": ("edm_dpm++_3m_sde", 6, dict(version="v2")),
+}
+
+
+class _IidNoiseSampler:
+    """Stand-in for k_diffusion.BrownianTreeNoiseSampler in the golden generator (see SAMPLER_CASES)."""
+
+    def __init__(self, x, sigma_min, sigma_max, seed=None, transform=lambda x: x):
+        self.x = x
+
+    def __call__(self, sigma, sigma_next):
+        return torch.randn_like(self.x)
+
+
+@torch.no_grad()
+def gen_samplers(R):
+    import importlib
+    from diffbir_amd import configs
+    kd = importlib.import_module("diffbir.sampler.k_diffusion")
+    kd.BrownianTreeNoiseSampler = _IidNoiseSampler
+    g = {}
+    built = {}
+    for name, (sampler, steps, kw) in SAMPLER_CASES.items():
+        kw = dict(kw)
+        ver = kw.pop("version", "v21")
+        if ver not in built:
+            built[ver] = build_reference(R, "tiny", configs.get("DIFFUSION_V21" if ver == "v21" else "DIFFUSION_V2"))
+        cldm, swin, diff, W = built[ver]
+        pipe = R.SwinIRPipeline(swin, cldm, diff, None, "cpu")
+        torch.manual_seed(17)
+        a = dict(cfg=4.0, rescale_cfg=False, s_churn=0, s_tmin=0, s_tmax=300, s_noise=1, eta=1, order=1)
+        a.update(kw)
+        with cases.quiet():
+            g[name] = pipe.run(cases.make_lq(3, 1, 512, 512), steps, 1.0, False, 512, 256, False, 256, False, 256, False,
+                               512, 256, "", cases.NEG_PROMPT, a["cfg"], "noise", sampler, 0, a["rescale_cfg"],
+                               a["s_churn"], a["s_tmin"], a["s_tmax"], a["s_noise"], a["eta"], a["order"])
+        print(name, g[name].shape, flush=True)
+    np.savez_compressed(os.path.join(OUT, "tiny_samplers.npz"), **g)
+
+
+TINY_PIPE_CASES = {   # tiny end-to-end cases of tests/golden/tiny_pipeline.npz (v2.1 schedule)
+    "spaced6_v21": ((3, 1, 512, 512), 6, "spaced", 231, {}),
+    "dpm10_v21": ((3, 1, 512, 512), 10, "dpm++_m2", 231, {}),
+    "spaced4_b2_v21": ((5, 2, 512, 512), 4, "spaced", 99, {}),
+    "spaced3_pad_v21": ((9, 1, 600, 712), 3, "spaced", 5, {}),
+    "spaced3_tiled_v21": ((9, 1, 600, 712), 3, "spaced", 5, dict(tiled=True)),
+    "dpm10_tiled_v21": ((9, 1, 600, 712), 10, "dpm++_m2", 5, dict(tiled=True)),
+}
+
+
+@torch.no_grad()
+def gen_ref_lowp(R):
+    """PSNR of the REFERENCE's own reduced-precision paths (cast_dtype + torch.autocast on CPU, what `--precision
+    fp16 / bf16` selects: loop.py:86-96,180) against its fp32 output, per tiny case: the yardstick for the engine's bf16
+    tolerance (bf16 carries 8 mantissa bits against fp16's 11: ~18 dB less, for the reference as for the engine)."""
+    import json
+    from diffbir_amd import configs
+    g = np.load(os.path.join(OUT, "tiny_pipeline.npz"))
+    res = {}
+    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        cldm, swin, diff, W = build_reference(R, "tiny", configs.get("DIFFUSION_V21"))
+        cldm.cast_dtype(dt)
+        for name, (lqspec, steps, sampler, seed, kw) in TINY_PIPE_CASES.items():
+            with torch.autocast("cpu", dt):
+                out = run_pipeline(R, cldm, swin, diff, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+            res[f"{name}_{tag}"] = cases.psnr_u8(out, g[name])
+            print(name, tag, f"{res[f'{name}_{tag}']:.2f} dB", flush=True)
+    with open(os.path.join(OUT, "reference_lowp_psnr.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
 def gen_host_tables(R):
     """Host-side tables of the path, straight from the reference's own functions: timestep spacing, the spaced
     sampler's registered buffers, the DPM-Solver discrete VP schedule, tile windows and blend weights."""
@@ -263,6 +352,10 @@ if __name__ == "__main__":
         gen_modules(R, "full", "full", 256, configs.get("DIFFUSION_V21"))
     elif what == "full_pipeline":
         gen_full_pipeline(R)
+    elif what == "samplers":
+        gen_samplers(R)
+    elif what == "ref_lowp":
+        gen_ref_lowp(R)
     elif what == "tokenizer":
         gen_tokenizer(R)
     elif what == "full_configs":

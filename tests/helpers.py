@@ -58,6 +58,42 @@ def run_option_case(pipe, name):
     return run_pipe(pipe, cases.make_lq(*lqspec), kw.pop("steps"), kw.pop("sampler"), kw.pop("seed"), **kw)
 
 
+# DDIM / EDM sampler cases (goldens: tests/golden/tiny_samplers.npz, oracle/make_golden.py SAMPLER_CASES)
+SAMPLER_CASES = {
+    "ddim8": ("ddim", 8, {}),
+    "ddim5_rescale": ("ddim", 5, dict(rescale_cfg=True, cfg=3.0)),
+    "edm_euler": ("edm_euler", 6, {}),
+    "edm_euler_churn": ("edm_euler", 6, dict(s_churn=4.0, s_tmin=0.05, s_tmax=50.0, s_noise=1.003)),
+    "edm_euler_a": ("edm_euler_a", 6, {}),
+    "edm_heun": ("edm_heun", 5, {}),
+    "edm_dpm_2": ("edm_dpm_2", 5, {}),
+    "edm_dpm_2_a": ("edm_dpm_2_a", 5, {}),
+    "edm_lms": ("edm_lms", 7, dict(order=3)),
+    "edm_dpm++_2s_a": ("edm_dpm++_2s_a", 5, {}),
+    "edm_dpm++_2m": ("edm_dpm++_2m", 8, {}),
+    "edm_dpm++_sde": ("edm_dpm++_sde", 5, {}),
+    "edm_dpm++_2m_sde": ("edm_dpm++_2m_sde", 8, {}),
+    "edm_dpm++_3m_sde": ("edm_dpm++_3m_sde", 10, {}),
+    "edm_dpm++_3m_sde_eps": ("edm_dpm++_3m_sde", 6, dict(version="v2")),
+}
+
+
+def run_sampler_case(pipe, name):
+    """Same call as oracle/make_golden.py gen_samplers; the SDE solvers get the i.i.d. stand-in for the Brownian tree
+    that the golden generator installed in the reference (torchsde is absent on both sides)."""
+    sampler, steps, kw = SAMPLER_CASES[name]
+    a = dict(cfg=4.0, rescale_cfg=False, s_churn=0, s_tmin=0, s_tmax=300, s_noise=1, eta=1, order=1)
+    a.update({k: v for k, v in kw.items() if k != "version"})
+    pipe.randn = cases.NoiseStream(17)
+    pipe.brownian = lambda x, randn: (lambda sigma, sigma_next: randn(tuple(x.shape)))
+    try:
+        return pipe.run(cases.make_lq(3, 1, 512, 512), steps, 1.0, False, 512, 256, False, 256, False, 256, False, 512, 256,
+                        "", cases.NEG_PROMPT, a["cfg"], "noise", sampler, 0, a["rescale_cfg"], a["s_churn"], a["s_tmin"],
+                        a["s_tmax"], a["s_noise"], a["eta"], a["order"])
+    finally:
+        pipe.brownian = None
+
+
 def rel_err(a, b):
     a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item(), (a - b).abs().max().item()

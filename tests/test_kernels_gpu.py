@@ -187,7 +187,7 @@ def test_conv3x3_fused_epilogue(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
-GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41]
+GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41, 44, 45]
 # 20 + t: tile t with pipelined fragment reads; 36-38: de-phased two-group variants; 40/41: K depth 32 (256x256)
 NO_GEGLU_TILES = (14, 15, 16, 34, 35, 37, 38)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
 
@@ -396,7 +396,7 @@ def test_phased_gemm_race_screen(dtype, tile13):
 
 
 # ------------------------------------------------------------------------------------------------ halo-patch conv kernel
-HALO_TILES = [50, 51]
+HALO_TILES = [50, 51, 52, 53]   # 50/51 de-phased wave groups, 52/53 lockstep + cross-tile fragment prefetch
 HALO_CASES = [
     # B, H, W, Cin, N  (stride 1, pad 1): 256-row tiles are whole image rows
     (2, 64, 64, 64, 160), (1, 128, 64, 128, 96), (2, 32, 32, 128, 200), (3, 16, 16, 64, 128), (5, 8, 8, 128, 320),

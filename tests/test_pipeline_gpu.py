@@ -11,7 +11,8 @@ import pytest
 import torch
 
 from oracle import cases
-from tests.helpers import OPTION_CASES, build_engine, rel_err, run_option_case, run_pipe
+from tests.helpers import (OPTION_CASES, SAMPLER_CASES, build_engine, rel_err, run_option_case, run_pipe,
+                           run_sampler_case)
 
 pytestmark = pytest.mark.gpu
 REPORT = {}
@@ -79,9 +80,19 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype,min_psnr", [(torch.float16, 45.0), (torch.bfloat16, 32.0)])
+# Tolerances.  fp16: the north_star bar, PSNR >= 45 dB against the reference's CPU-fp32 output.  bf16 carries 8 mantissa
+# bits against fp16's 11 (20*log10(2^3) = 18 dB less for ANY implementation): the yardstick is the REFERENCE ITSELF run
+# with `--precision bf16` semantics (cast_dtype + autocast) against its own fp32 output, recorded per case in
+# tests/golden/reference_lowp_psnr.json (36.2 .. 40.2 dB; its fp16 path: 52.3 .. 54.7 dB).  The engine must stay within
+# 1.5 dB of the reference's own bf16 result (it is above it on every case measured) and above an absolute 34 dB floor.
+@pytest.mark.parametrize("dtype,min_psnr", [(torch.float16, 45.0), (torch.bfloat16, 34.0)])
 @pytest.mark.parametrize("name,dcfg,lqspec,steps,sampler,seed,kw", CASES, ids=[c[0] for c in CASES])
 def test_tiny_pipeline_vs_reference_golden(golden_dir, name, dcfg, lqspec, steps, sampler, seed, kw, dtype, min_psnr):
+    if dtype == torch.bfloat16:
+        with open(os.path.join(golden_dir, "reference_lowp_psnr.json")) as f:
+            ref_lowp = json.load(f)
+        if f"{name}_bf16" in ref_lowp:
+            min_psnr = max(min_psnr, ref_lowp[f"{name}_bf16"] - 1.5)
     dev = _dev()
     pipe, cldm, swin = build_engine("tiny", dcfg, dev, dtype)
     ref = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))[name]
@@ -106,6 +117,20 @@ def test_tiny_pipeline_options_vs_reference_golden(golden_dir, name):
     assert out.shape == ref.shape and psnr >= 45.0, psnr
 
 
+@pytest.mark.parametrize("name", sorted(SAMPLER_CASES))
+def test_ddim_edm_samplers_vs_reference_golden(golden_dir, name):
+    """DDIM + the eleven EDM / k-diffusion solvers on the HIP kernels (fp16) against the unmodified reference."""
+    dev = _dev()
+    dcfg = "DIFFUSION_V2" if SAMPLER_CASES[name][2].get("version") == "v2" else "DIFFUSION_V21"
+    pipe, cldm, swin = build_engine("tiny", dcfg, dev, torch.float16)
+    ref = np.load(os.path.join(golden_dir, "tiny_samplers.npz"))[name]
+    out = run_sampler_case(pipe, name)
+    psnr = cases.psnr_u8(out, ref)
+    REPORT[f"tiny_sampler_{name}_fp16"] = psnr
+    print(name, f"PSNR {psnr:.2f} dB")
+    assert out.shape == ref.shape and psnr >= 45.0, psnr
+
+
 def test_full_pipeline_50_steps_vs_reference_golden(golden_dir):
     """BASELINE config C1/C2 semantics at batch 1: 512x512, 50 spaced steps, CFG 4.0, v2.1 — PSNR >= 45 dB (fp16)
     against the unmodified reference's CPU fp32 output."""
@@ -117,6 +142,39 @@ def test_full_pipeline_50_steps_vs_reference_golden(golden_dir):
     REPORT["full_spaced50_v21_fp16"] = psnr
     print(f"full 50-step pipeline PSNR {psnr:.2f} dB")
     assert psnr >= 45.0, psnr
+
+
+# BASELINE.json configs at FULL network size (goldens: oracle/make_golden.py FULL_CONFIG_CASES, the unmodified reference on
+# CPU fp32): C2 at batch 2 (the benchmark's spaced-50 + CFG path with a batched evaluation), C3 (DPM-Solver++(2M), 20
+# steps, batch 2) and C4's scheduler at full size (1024x1024, tile 512 / stride 256: 9 tiles, 10 spaced steps).
+FULL_CONFIG_CASES = {
+    "c2_spaced50_b2": ((21, 2, 512, 512), 50, "spaced", 231, {}),
+    "c3_dpm20_b2": ((22, 2, 512, 512), 20, "dpm++_m2", 231, {}),
+    "c4_tiled1024_spaced10": ((23, 1, 1024, 1024), 10, "spaced", 231, dict(tiled=True, tile=512, stride=256)),
+}
+
+
+@pytest.fixture(scope="module")
+def full_engine():
+    dev = _dev()
+    return build_engine("full", "DIFFUSION_V21", dev, torch.float16)
+
+
+@pytest.mark.parametrize("name", sorted(FULL_CONFIG_CASES))
+def test_full_baseline_configs_vs_reference_golden(golden_dir, full_engine, name):
+    """PSNR >= 45 dB (north_star tolerance, fp16) of the engine's uint8 output against the reference's, per image."""
+    path = os.path.join(golden_dir, f"full_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    pipe, cldm, swin = full_engine
+    lqspec, steps, sampler, seed, kw = FULL_CONFIG_CASES[name]
+    ref = np.load(path)["out"]
+    out = run_pipe(pipe, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+    assert out.shape == ref.shape
+    per_image = [cases.psnr_u8(out[i], ref[i]) for i in range(out.shape[0])]
+    REPORT[f"full_{name}_fp16"] = per_image
+    print(name, "PSNR per image", [f"{p:.2f}" for p in per_image])
+    assert min(per_image) >= 45.0, per_image
 
 
 def test_tiled_equals_untiled_when_single_tile():
@@ -153,3 +211,24 @@ def test_batch_independence():
         pipe.randn = lambda shape: next(it)
         one = pipe.run(lq[i:i + 1], *args)
         assert cases.psnr_u8(one, both[i:i + 1]) > 55.0
+
+
+def test_vae_attention_query_chunking_is_exact():
+    """The VAE mid-block attention runs over query chunks (no [L, L] score matrix: 137 GB at 4096x4096).  Chunking must
+    not change a single bit: every query row still sees all keys (also with a ragged last chunk and L % 64 != 0)."""
+    from diffbir_amd.model import vae as vae_mod
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    rs = cases.NoiseStream(3)
+    for hw in ((24, 40), (15, 23)):               # L = 960 / 345 tokens
+        z = rs((2, 4) + hw).to(dev)
+        x = torch.tensor(cases.make_lq(4, 2, hw[0] * 8, hw[1] * 8)).float().div(255).permute(0, 3, 1, 2).contiguous().to(dev)
+        full_d, full_e = cldm.vae_decode(z), cldm.vae.encode_mode(x, 0.18215, 2.0, -1.0)
+        old = vae_mod.ATTN_CHUNK_BYTES
+        try:
+            Lp = (hw[0] * hw[1] + 63) // 64 * 64
+            vae_mod.ATTN_CHUNK_BYTES = 2 * 2 * Lp * 256      # 256 query rows per chunk -> 4 / 2 chunks, last one ragged
+            assert torch.equal(cldm.vae_decode(z), full_d)
+            assert torch.equal(cldm.vae.encode_mode(x, 0.18215, 2.0, -1.0), full_e)
+        finally:
+            vae_mod.ATTN_CHUNK_BYTES = old
