@@ -56,6 +56,45 @@ __device__ __forceinline__ void gemm_epilogue(const dbir_gemm_desc& d, const Epi
     }
     return;
   }
+  if (d.out_f32) {
+    // f32 output (network heads with a handful of channels: UNet `out` 320 -> 4, unet.py:678): each lane stores its 4
+    // consecutive channels straight from registers as one float4 (ldc % 4 == 0, no residual / GEGLU / transposed store)
+    float* __restrict__ Cf = reinterpret_cast<float*>(d.C) + (long long)bz * d.strideC_z;
+    const u16* __restrict__ RVf = reinterpret_cast<const u16*>(d.rowvec);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = tm * BM + wm * 32 * MI + i * 32 + lq;
+      if (m >= M) continue;
+      const u16* rvp = RVf ? RVf + (long long)(m / d.rows_per_batch) * d.rowvec_ld : nullptr;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = tn * BN + wn * 32 * NJ + j * 32 + 8 * g + 4 * hi;
+          if (n0 >= N) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[i][j][4 * g + e];
+            if (d.bias && n0 + e < N) x += d.bias[n0 + e];
+            if (rvp && n0 + e < N) x += T::to_f32(rvp[n0 + e]);
+            if (d.act == DBIR_ACT_SILU) x = silu_f(x);
+            else if (d.act == DBIR_ACT_GELU) x = gelu_fast(x);
+            else if (d.act == DBIR_ACT_LRELU) x = x > 0.f ? x : x * d.act_param;
+            v[e] = x * d.out_scale;
+          }
+          float* dst = Cf + (long long)m * d.ldc + n0;
+          if (n0 + 4 <= N) {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < N) dst[e] = v[e];
+          }
+        }
+    }
+    return;
+  }
   // ---------------- epilogue: f32 math in registers -> 16-bit tile in LDS -> row-contiguous 16 B stores ----------
   const bool geglu = d.act == DBIR_ACT_GEGLU;
   const int bn_out = geglu ? BN / 2 : BN;

@@ -624,7 +624,15 @@ int dbir_splitk_reduce_launch(const dbir_gemm_desc& d, int splitk, float* ws, hi
 
 // Is the descriptor (already validated by dbir_gemm) runnable on the direct-to-LDS kernel?
 bool dbir_gemm_glds_eligible(const dbir_gemm_desc& d) {
-  if (d.out_f32) return false;
+  if (d.out_f32) {  // direct float4 stores from the accumulators: plain epilogues only
+    if (d.store_mode != 0 || d.R || d.act == DBIR_ACT_GEGLU || d.splitk > 1 || d.ldc % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(d.C) & 15) || d.strideC_z % 4 != 0)
+      return false;
+    if ((reinterpret_cast<uintptr_t>(d.A) & 15) || (reinterpret_cast<uintptr_t>(d.W) & 15)) return false;
+    if (d.strideA_z % 8 || d.strideW_z % 8) return false;
+    if (d.mode == DBIR_MODE_LINEAR) return d.K % BK == 0 && d.lda % 8 == 0;
+    return d.Cin % BK == 0 && (long long)d.B * d.Hi * d.Wi < 2147483647LL;
+  }
   if (d.store_mode == 1) {  // transposed store: whole 8-row chunks inside one batch, 16-byte aligned destinations
     if (d.trans_L % 8 != 0 || d.trans_ld % 8 != 0 || d.trans_bstride % 8 != 0 || d.R || d.act == DBIR_ACT_GEGLU ||
         d.splitk > 1 || d.batch > 1)

@@ -524,6 +524,8 @@ int dbir_gemm_halo(const dbir_gemm_desc& dd, int tile, hipStream_t s) {
       return f16 ? launch_halo<F16, 8, 1, 1, 5, 384>(p, s) : launch_halo<BF16, 8, 1, 1, 5, 384>(p, s);
     case 51:  // 256x128, 8 waves (64x64 each)
       return f16 ? launch_halo<F16, 4, 2, 2, 2, 384>(p, s) : launch_halo<BF16, 4, 2, 2, 2, 384>(p, s);
+    case 54:  // 256x32, 8 waves (32x32 each): heads with a handful of output channels (UNet `out`: 320 -> 4, f32 store)
+      return f16 ? launch_halo<F16, 8, 1, 1, 1, 384, 0, 1>(p, s) : launch_halo<BF16, 8, 1, 1, 1, 384, 0, 1>(p, s);
     case 52:  // 256x160, lockstep schedule with cross-tile fragment prefetch
       return f16 ? launch_halo<F16, 8, 1, 1, 5, 384, 0, 1>(p, s) : launch_halo<BF16, 8, 1, 1, 5, 384, 0, 1>(p, s);
     case 53:  // 256x128, lockstep schedule

@@ -198,7 +198,7 @@ def apply_tile_code(d: GemmDesc, code: int, device) -> None:
 def _gemm_launch(d: GemmDesc, keep):
     out = keep[2]
     from_table = False
-    if d.tile == 0 and not d.out_f32:
+    if d.tile == 0:
         code = _TUNER.run(d, out) if _TUNER is not None else tuning.lookup(d)
         from_table = code != 0
         apply_tile_code(d, code, out.device)

@@ -3,8 +3,13 @@
 `dbir_gemm` (C side) has a built-in heuristic (tile id 0).  On top of it this module holds a measured table
 `tuning_gfx950.json` — problem key -> tile id — produced ON the MI355X by `tools/autotune.py`, which times every
 eligible tile variant on the exact launches of the pipeline (same strides, epilogues, alignment) and validates each
-variant's output against the default kernel before accepting it.  Lookups happen in `ops._gemm_launch`; a missing file
-or key falls back to the C heuristic.  `DBIR_TUNING=0` disables the table, `DBIR_TUNING_FILE` overrides its path.
+variant's output against the default kernel before accepting it.  Lookups happen in `ops._gemm_launch`: exact key
+first; otherwise the entry of the same problem class (mode, N, K, epilogue, stride ...) whose M is nearest within a
+factor of two (the table is measured at the benchmark's batch — 16 samples per evaluation; other batches, e.g. config
+C3's 8 or the tiled scheduler's 32-sample chunks, land on the neighbouring M bucket instead of the C heuristic; a
+variant that cannot run the neighbouring shape is refused by `dbir_gemm` and the launch falls back to the heuristic).
+A missing file or class falls back to the C heuristic.  `DBIR_TUNING=0` disables the table, `DBIR_TUNING_FILE`
+overrides its path.
 """
 import json
 import os
@@ -13,12 +18,13 @@ from typing import Dict, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "tuning_gfx950.json")
 _table: Optional[Dict[str, int]] = None
+_classes: Dict[str, list] = {}      # key without M -> [(M, tile)]
 
 
 def key_of(d) -> str:
     """Problem key of a GemmDesc: everything that changes which tile wins."""
     return (f"{d.mode}:{d.M}:{d.N}:{d.K}:a{d.act}:s{d.stride}:u{d.upsample}:z{max(d.batch, 1)}:"
-            f"r{1 if d.R else 0}:v{1 if d.rowvec else 0}{':T' if d.store_mode else ''}")
+            f"r{1 if d.R else 0}:v{1 if d.rowvec else 0}{':T' if d.store_mode else ''}{':f' if d.out_f32 else ''}")
 
 
 def load(path: Optional[str] = None) -> Dict[str, int]:
@@ -34,9 +40,23 @@ def load(path: Optional[str] = None) -> Dict[str, int]:
         for k, v in raw.get("tiles", raw).items():
             tab[k] = int(v["tile"] if isinstance(v, dict) else v)
     _table = tab
+    _classes.clear()
+    for k, t in tab.items():
+        parts = k.split(":")
+        _classes.setdefault(":".join(parts[:1] + parts[2:]), []).append((int(parts[1]), t))
     return tab
 
 
 def lookup(d) -> int:
     tab = _table if _table is not None else load()
-    return tab.get(key_of(d), 0)
+    key = key_of(d)
+    hit = tab.get(key)
+    if hit is not None:
+        return hit
+    parts = key.split(":")
+    best, best_r = 0, 2.0 + 1e-9
+    for m, t in _classes.get(":".join(parts[:1] + parts[2:]), ()):
+        r = max(m, d.M) / max(min(m, d.M), 1)
+        if r <= best_r and t:
+            best, best_r = t, r
+    return best

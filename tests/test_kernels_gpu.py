@@ -444,6 +444,24 @@ def test_halo_conv3x3_fused_epilogue_and_splitk(tile, dtype):
         assert torch.equal(got, ops.conv3x3(x, pw, rowvec=emb, residual=res, act=emu.ACT_SILU, out_scale=0.7, tile=code))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 5, 10, 37, 50, 52, 54])
+def test_conv3x3_f32_head(tile, dtype):
+    """f32-output heads (UNet `out` 320 -> 4): direct float4 stores from the accumulators in the direct-to-LDS kernels;
+    tile 54 = 256x32 halo tile for a handful of output channels."""
+    for (B, H, W, Cin, N) in ((2, 64, 64, 320, 4), (3, 16, 16, 128, 8), (2, 32, 32, 64, 3)):
+        x = rnd(B, H, W, Cin, dtype=dtype)
+        pw = ops.pack_conv3x3(rnd(N, Cin, 3, 3, dtype=torch.float32, s=(9 * Cin) ** -0.5, seed=1).cpu(),
+                              rnd(N, dtype=torch.float32, seed=2).cpu(), dtype, DEV)
+        if N % 4 != 0 and tile != 0:
+            with pytest.raises(Exception):   # f32 rows must stay 16-byte aligned for the float4 stores
+                ops.conv3x3(x, pw, out_f32=True, tile=tile)
+            continue
+        got = ops.conv3x3(x, pw, out_f32=True, tile=tile)
+        assert got.dtype == torch.float32
+        check(f"conv3x3 f32 head {B}x{H}x{W}x{Cin}->{N} t{tile}", got, emu.conv3x3(x, pw, out_f32=True), torch.float32, 4.0)
+
+
 @pytest.mark.parametrize("tile", HALO_TILES)
 def test_halo_rejects_ineligible(tile):
     """tiles 50 / 51 are only valid when 256-row tiles are whole image rows of a stride-1 conv; everything else must be

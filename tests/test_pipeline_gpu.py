@@ -119,7 +119,17 @@ def test_tiny_pipeline_options_vs_reference_golden(golden_dir, name):
 
 @pytest.mark.parametrize("name", sorted(SAMPLER_CASES))
 def test_ddim_edm_samplers_vs_reference_golden(golden_dir, name):
-    """DDIM + the eleven EDM / k-diffusion solvers on the HIP kernels (fp16) against the unmodified reference."""
+    """DDIM + the eleven EDM / k-diffusion solvers on the HIP kernels (fp16) against the unmodified reference (fp32).
+    Bar: 45 dB — except where the reference's OWN fp16 run (tests/golden/reference_lowp_psnr.json, `sampler_*_fp16`) cannot
+    reach it: the second-order solvers (Heun, DPM-2, DPM-2 ancestral) amplify the 16-bit error of their second network
+    evaluation ~500x in the first step out of sigma_0 = 1e4 (reference: 41.8 - 43.2 dB); there the engine must stay
+    within 1 dB of the reference's fp16 result.  eps-parameterisation at sigma = 1e4 (`*_eps`) cancels completely in
+    fp16 on both sides (5.7 dB, identical garbage): covered in f32 by the CPU wiring test only."""
+    if name.endswith("_eps"):
+        pytest.skip("eps-parameterisation from sigma_0 = 1e4 is meaningless in fp16 (reference: 5.7 dB too)")
+    with open(os.path.join(golden_dir, "reference_lowp_psnr.json")) as f:
+        yard = json.load(f).get(f"sampler_{name}_fp16")
+    bar = 45.0 if yard is None else min(45.0, yard - 1.0)
     dev = _dev()
     dcfg = "DIFFUSION_V2" if SAMPLER_CASES[name][2].get("version") == "v2" else "DIFFUSION_V21"
     pipe, cldm, swin = build_engine("tiny", dcfg, dev, torch.float16)
@@ -127,8 +137,8 @@ def test_ddim_edm_samplers_vs_reference_golden(golden_dir, name):
     out = run_sampler_case(pipe, name)
     psnr = cases.psnr_u8(out, ref)
     REPORT[f"tiny_sampler_{name}_fp16"] = psnr
-    print(name, f"PSNR {psnr:.2f} dB")
-    assert out.shape == ref.shape and psnr >= 45.0, psnr
+    print(name, f"PSNR {psnr:.2f} dB (bar {bar:.1f})")
+    assert out.shape == ref.shape and psnr >= bar, (psnr, bar)
 
 
 def test_full_pipeline_50_steps_vs_reference_golden(golden_dir):
