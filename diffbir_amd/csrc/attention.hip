@@ -22,159 +22,10 @@ constexpr int KT = 64;        // keys per tile
 constexpr int K_LD = 64 + 8;  // K tile row (halfs): 144 B -> conflict-free ds_read_b128
 constexpr int V_LD = 64 + 4;  // V^T tile row (halfs): 136 B -> conflict-free ds_read_b64
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_kernel(const u16* __restrict__ Q, long long q_bs, long long ldq,
-                                                   const u16* __restrict__ K, long long k_bs, long long ldk,
-                                                   const u16* __restrict__ Vt, long long vt_bs, long long ldvt,
-                                                   u16* __restrict__ O, long long o_bs, long long ldo, int H,
-                                                   int Lq, int Lk, float scale_log2e) {
-  __shared__ __attribute__((aligned(16))) u16 Ks[KT * K_LD];
-  __shared__ __attribute__((aligned(16))) u16 Vs[64 * V_LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hi = lane >> 5, lq = lane & 31;
-  const int b = blockIdx.y / H, h = blockIdx.y % H;
-  const int q_row = blockIdx.x * 128 + wave * 32 + lq;
-  const bool q_ok = q_row < Lq;
-
-  // Q fragments (B operand): lane holds Q[q][16*ks + 8*hi .. +7], ks = 0..3
-  typename T::vec8 qf[4];
-  {
-    const u16* qp = Q + (long long)b * q_bs + (long long)(q_ok ? q_row : 0) * ldq + h * 64 + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      uint4 v = q_ok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
-      qf[ks] = __builtin_bit_cast(typename T::vec8, v);
-    }
-  }
-  f32x16 o_acc[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  const u16* Kg = K + (long long)b * k_bs + h * 64;
-  const u16* Vg = Vt + (long long)b * vt_bs + (long long)(h * 64) * ldvt;
-  const int kc = tid & 7, r0 = tid >> 3;  // staging: 16-byte chunk kc of row r0 (+32)
-
-  const int ntiles = (Lk + KT - 1) / KT;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int key0 = kt * KT;
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K tile [key][d] and V^T tile [d][key] ----
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = r0 + 32 * i;
-      const int key = key0 + row;
-      uint4 kv = make_uint4(0, 0, 0, 0);
-      if (key < Lk) kv = *reinterpret_cast<const uint4*>(Kg + (long long)key * ldk + kc * 8);
-      *reinterpret_cast<uint4*>(&Ks[row * K_LD + kc * 8]) = kv;
-      // V^T: row = d, chunk = keys key0 + kc*8 .. +7
-      const int kcol = key0 + kc * 8;
-      uint4 vv = make_uint4(0, 0, 0, 0);
-      if (kcol < Lk) {
-        vv = *reinterpret_cast<const uint4*>(Vg + (long long)row * ldvt + kcol);
-        if (kcol + 8 > Lk) {  // zero the tail beyond Lk (pad columns may hold anything)
-          u16* hv = reinterpret_cast<u16*>(&vv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (kcol + e >= Lk) hv[e] = 0;
-        }
-      }
-      // V_LD rows are 8-byte aligned only: write as two 8-byte halves
-      uint2* dst = reinterpret_cast<uint2*>(&Vs[row * V_LD + kc * 8]);
-      dst[0] = make_uint2(vv.x, vv.y);
-      dst[1] = make_uint2(vv.z, vv.w);
-    }
-    __syncthreads();
-
-    // ---- S^T = K Q^T : two 32-key blocks x 4 d-steps ----
-    f32x16 s_acc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        typename T::vec8 kf =
-            *reinterpret_cast<const typename T::vec8*>(&Ks[(kb * 32 + lq) * K_LD + ks * 16 + hi * 8]);
-        s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
-      }
-    }
-    // ---- online softmax (log2 domain) ----
-    float mx = -1e30f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float sv = s_acc[kb][r] * scale_log2e;
-        sv = key < Lk ? sv : -1e30f;
-        s_acc[kb][r] = sv;
-        mx = fmaxf(mx, sv);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s_acc[kb][r] - m_new);
-        s_acc[kb][r] = pv;
-        psum += pv;
-      }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
-
-    // ---- O^T += V^T P^T : 4 key-steps x 2 d-tiles ----
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float pf[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = s_acc[s >> 1][8 * (s & 1) + j];
-      const uint4 pp = pack8<T>(pf);
-      const typename T::vec8 pfrag = __builtin_bit_cast(typename T::vec8, pp);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const u16* vrow = &Vs[(t * 32 + lq) * V_LD + 16 * s + 4 * hi];
-        const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
-        const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
-        const uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
-        o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
-      }
-    }
-  }
-
-  // ---- epilogue: O[q][d] = O^T[d][q] / l ----
-  if (q_ok) {
-    const float inv = 1.0f / l_run;
-    u16* op = O + (long long)b * o_bs + (long long)q_row * ldo + h * 64;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u16 hv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = T::from_f32(o_acc[t][4 * g + e] * inv);
-        uint2 pk;
-        pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
-        pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
-        *reinterpret_cast<uint2*>(op + t * 32 + 8 * g + 4 * hi) = pk;
-      }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Variant 2 (default): same decomposition and register dataflow as attn_kernel above, restructured for issue slots.
-// At head_dim 64 a 64-key tile is only 16 MFMAs (512 matrix cycles) per wave against >300 VALU ops of softmax in
-// variant 1, so the kernel is VALU-bound; and its K/V staging is synchronous (global -> LDS between two barriers).
+// Self-attention kernel (any Lk): the decomposition and register dataflow described at the top of this file.
+// At head_dim 64 a 64-key tile is only 16 MFMAs (512 matrix cycles) per wave against >300 VALU ops of a naive
+// softmax, so the kernel is VALU-bound; hence:
 //   * K / V^T tiles are double-buffered in LDS; the next tile's global loads are issued into registers BEFORE the
 //     current tile's MFMAs and written to the other buffer after them (guide T14): one barrier per tile, L2/HBM
 //     latency hidden under the compute.
@@ -403,11 +254,151 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-attention kernel (Lk <= 96: the 77-token text context, reference attention.py:189-216 with context != x).
+// The whole K [Lk][64] and V^T [64][Lk] of one (batch, head) fit in 26 KB of LDS: they are staged ONCE per workgroup,
+// which then walks `qpb` consecutive 128-query blocks with no further barrier; all keys sit in one tile, so the softmax
+// is a single exact pass (no running max / rescale) — S^T = K Q^T (3 key blocks x 4 d-steps), p = exp2(s*c - m),
+// O^T = V^T P^T (6 key-steps x 2 d-tiles), same register dataflow as attn2_kernel.  The generic kernel re-stages K / V^T
+// through registers for every 128-query block behind two barriers: 154-185 TF/s at Lk = 77 (profiles/r1_attention_ab*).
+constexpr int XK = 96;             // padded key count
+constexpr int XV_LD = XK + 4;      // V^T row (halfs): 200 B -> conflict-free ds_read_b64
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_cross_kernel(const u16* __restrict__ Q, long long q_bs, long long ldq,
+                                                            const u16* __restrict__ K, long long k_bs, long long ldk,
+                                                            const u16* __restrict__ Vt, long long vt_bs, long long ldvt,
+                                                            u16* __restrict__ O, long long o_bs, long long ldo, int H,
+                                                            int Lq, int Lk, float c, int qpb) {
+  __shared__ __attribute__((aligned(16))) u16 lds[XK * K_LD + 64 * XV_LD];
+  u16* Ks = lds;
+  u16* Vs = lds + XK * K_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int nqb = (Lq + 127) / 128, ngrp = (nqb + qpb - 1) / qpb;
+  const int bh = blockIdx.x / ngrp, grp = blockIdx.x % ngrp;
+  const int b = bh / H, h = bh % H;
+  const u16* Kg = K + (long long)b * k_bs + h * 64;
+  const u16* Vg = Vt + (long long)b * vt_bs + (long long)(h * 64) * ldvt;
+  // ---- stage K (rows >= Lk zero) and V^T (columns >= Lk zero) once ----
+  for (int q = tid; q < XK * 8; q += 256) {
+    const int row = q >> 3, kc = q & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0);
+    if (row < Lk) kv = *reinterpret_cast<const uint4*>(Kg + (long long)row * ldk + kc * 8);
+    *reinterpret_cast<uint4*>(&Ks[row * K_LD + kc * 8]) = kv;
+  }
+  for (int q = tid; q < 64 * (XK / 8); q += 256) {
+    const int row = q / (XK / 8), kc = q % (XK / 8);
+    const int kcol = kc * 8;
+    uint4 vv = make_uint4(0, 0, 0, 0);
+    if (kcol < Lk) {
+      vv = *reinterpret_cast<const uint4*>(Vg + (long long)row * ldvt + kcol);
+      if (kcol + 8 > Lk) {
+        u16* hv = reinterpret_cast<u16*>(&vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (kcol + e >= Lk) hv[e] = 0;
+      }
+    }
+    uint2* dst = reinterpret_cast<uint2*>(&Vs[row * XV_LD + kcol]);
+    dst[0] = make_uint2(vv.x, vv.y);
+    dst[1] = make_uint2(vv.z, vv.w);
+  }
+  __syncthreads();
+
+  for (int qi = 0; qi < qpb; ++qi) {
+    const int qb = grp * qpb + qi;
+    if (qb >= nqb) break;
+    const int q_row = qb * 128 + wave * 32 + lq;
+    const bool q_ok = q_row < Lq;
+    typename T::vec8 qf[4];
+    {
+      const u16* qp = Q + (long long)b * q_bs + (long long)(q_ok ? q_row : 0) * ldq + h * 64 + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint4 v = q_ok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
+        qf[ks] = __builtin_bit_cast(typename T::vec8, v);
+      }
+    }
+    f32x16 s_acc[3];
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        typename T::vec8 kf =
+            *reinterpret_cast<const typename T::vec8*>(&Ks[(kb * 32 + lq) * K_LD + ks * 16 + hi * 8]);
+        s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float sv = key < Lk ? s_acc[kb][r] : -1e30f;
+        s_acc[kb][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float neg_m = -mx * c;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], c, neg_m));  // masked keys: exp2(-huge) = 0
+        s_acc[kb][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      float pf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = s_acc[s >> 1][8 * (s & 1) + j];
+      const uint4 pp = pack8<T>(pf);
+      const typename T::vec8 pfrag = __builtin_bit_cast(typename T::vec8, pp);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u16* vrow = &Vs[(t * 32 + lq) * XV_LD + 16 * s + 4 * hi];
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+        const uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
+      }
+    }
+    if (q_ok) {
+      const float inv = 1.0f / psum;
+      u16* op = O + (long long)b * o_bs + (long long)q_row * ldo + h * 64;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u16 hv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = T::from_f32(o_acc[t][4 * g + e] * inv);
+          uint2 pk;
+          pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+          pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+          *reinterpret_cast<uint2*>(op + t * 32 + 8 * g + 4 * hi) = pk;
+        }
+    }
+  }
+}
+
 int g_attn_variant = 2;
 
 }  // namespace
 
-// tuning / A-B switch (dbir_set_option): 1 = synchronous-staging kernel, 2 = double-buffered + VALU-diet kernel
+// A/B switch (dbir_set_option): 2 = default (cross kernel for Lk <= 96, generic otherwise), 3 = generic kernel always
 void dbir_attention_set_variant(int v) { g_attn_variant = v; }
 
 extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, long long ldq, const void* K,
@@ -422,34 +413,37 @@ extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, lon
   DBIR_CHECK_ARG(ldvt >= ((Lk + 7) / 8) * 8, "dbir_attention: ldvt %lld too small for Lk %d", ldvt, Lk);
   DBIR_CHECK_ARG((long long)B * H <= 65535, "dbir_attention: B*H too large for gridDim.y");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid(cdiv(Lq, 128), B * H);
   const float sl2 = scale * 1.4426950408889634f;
   if (dtype != DBIR_F16 && dtype != DBIR_BF16) {
     dbir_set_error("dbir_attention: bad dtype %d", dtype);
     return DBIR_ERR_ARG;
   }
-  if (g_attn_variant == 2) {
-    DBIR_CHECK_ARG((long long)cdiv(Lq, 128) * B * H < 2147483647LL, "dbir_attention: grid too large");
-    const dim3 grid1((unsigned)(cdiv(Lq, 128) * B * H));
+  // text-context cross-attention with K / V^T resident in LDS (3 = A/B: generic kernel).  At Lk = 77 the op is HBM-bound
+  // (Q in + O out = 84 MB for 6.5 GFLOP at the 64x64 level: 77 FLOP/B against a ridge of ~400): measured 29.3 vs 34.7 us
+  // there (2.9 TB/s), but below ~2048 query blocks the generic kernel's finer grid wins (profiles/r2_attention_ab.log)
+  if (Lk <= XK && g_attn_variant != 3 && (long long)cdiv(Lq, 128) * B * H >= 2048) {
+    const int nqb = cdiv(Lq, 128);
+    // enough workgroups to fill 256 CUs x 2, each amortising its K / V^T staging over up to 8 query blocks
+    int qpb = 8;
+    while (qpb > 1 && (long long)cdiv(nqb, qpb) * B * H < 1024) qpb >>= 1;
+    const dim3 gridx((unsigned)(cdiv(nqb, qpb) * B * H));
     if (dtype == DBIR_F16)
-      hipLaunchKernelGGL((attn2_kernel<F16>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
-                         k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
+      hipLaunchKernelGGL((attn_cross_kernel<F16>), gridx, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
+                         k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2, qpb);
     else
-      hipLaunchKernelGGL((attn2_kernel<BF16>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
-                         k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
-    DBIR_CHECK_LAUNCH("dbir_attention");
+      hipLaunchKernelGGL((attn_cross_kernel<BF16>), gridx, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
+                         k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2, qpb);
+    DBIR_CHECK_LAUNCH("dbir_attention(cross)");
     return DBIR_OK;
   }
+  DBIR_CHECK_ARG((long long)cdiv(Lq, 128) * B * H < 2147483647LL, "dbir_attention: grid too large");
+  const dim3 grid1((unsigned)(cdiv(Lq, 128) * B * H));
   if (dtype == DBIR_F16)
-    hipLaunchKernelGGL((attn_kernel<F16>), grid, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
+    hipLaunchKernelGGL((attn2_kernel<F16>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
                        k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
-  else if (dtype == DBIR_BF16)
-    hipLaunchKernelGGL((attn_kernel<BF16>), grid, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
+  else
+    hipLaunchKernelGGL((attn2_kernel<BF16>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
                        k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
-  else {
-    dbir_set_error("dbir_attention: bad dtype %d", dtype);
-    return DBIR_ERR_ARG;
-  }
   DBIR_CHECK_LAUNCH("dbir_attention");
   return DBIR_OK;
 }

@@ -11,6 +11,10 @@ namespace {
 //  2. gn_apply: grid (nblk, B). Every block first sums the nchunk partials of its sample in a fixed order
 //               (<= 64 x 64 floats, L2 resident) -> mean / rstd per group in LDS, folds them with gamma / beta into
 //               per-thread coefficients, then streams y = act(x*a + s).
+// Numerics: the sums are SHIFTED — sum (x - p_g), sum (x - p_g)^2 with the pivot p_g = x[b, row 0, first channel of
+// group g] (any constant gives the exact variance in exact arithmetic; one near the data removes the cancellation of
+// E[x^2] - mean^2 when |mean| >> std, e.g. large-offset VAE activations over groups of ~4M elements; PyTorch's
+// group_norm, which the reference calls, uses a Welford-type update for the same reason).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void gn_stats(const u16* __restrict__ x, long long ldx, float* __restrict__ partial, int HW, int C,
@@ -22,9 +26,16 @@ __global__ void gn_stats(const u16* __restrict__ x, long long ldx, float* __rest
   const int cv = t % CV, rsub = t / CV;
   const int r_begin = chunk * rows_per_chunk;
   const int r_end = min(HW, r_begin + rows_per_chunk);
-  float s[8], ss[8];
+  float s[8], ss[8], pv[8];
+  {
+    const int cpg_ = C / groups;
+    const u16* x0 = x + (long long)b * HW * ldx;   // row 0 of this sample
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    for (int e = 0; e < 8; ++e) {
+      s[e] = ss[e] = 0.f;
+      pv[e] = T::to_f32(x0[((cv * 8 + e) / cpg_) * cpg_]);
+    }
+  }
   const u16* xb = x + (long long)b * HW * ldx + cv * 8;
   int r = r_begin + rsub;
   for (; r + 3 * rpi < r_end; r += 4 * rpi) {  // 4 independent 16-byte loads in flight per thread
@@ -37,8 +48,9 @@ __global__ void gn_stats(const u16* __restrict__ x, long long ldx, float* __rest
       unpack8<T>(v[u], f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s[e] += f[e];
-        ss[e] += f[e] * f[e];
+        const float dl = f[e] - pv[e];
+        s[e] += dl;
+        ss[e] += dl * dl;
       }
     }
   }
@@ -48,8 +60,9 @@ __global__ void gn_stats(const u16* __restrict__ x, long long ldx, float* __rest
     unpack8<T>(v, f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      s[e] += f[e];
-      ss[e] += f[e] * f[e];
+      const float dl = f[e] - pv[e];
+      s[e] += dl;
+      ss[e] += dl * dl;
     }
   }
   float* mine = sh + (long long)rsub * 2 * C;
@@ -79,12 +92,19 @@ template <typename T>
 __global__ void gn_apply(const u16* __restrict__ x, long long ldx, u16* __restrict__ y, long long ldy,
                          const float* __restrict__ partial, const float* __restrict__ gamma,
                          const float* __restrict__ beta, int nchunk, int HW, int C, int groups, float eps,
-                         int rows_per_blk, int rpi, int silu) {
+                         int rows_per_blk, int rpi, int silu, const float* __restrict__ ext) {
   __shared__ float stat[128];  // mean[groups], rstd[groups]
   const int CV = C >> 3;
   const int t = threadIdx.x;
   const int b = blockIdx.y;
   const int cpg = C / groups;
+  if (ext) {   // statistics supplied by the caller (tiled VAE: aggregated over tiles): [B][mean(groups) | var(groups)]
+    if (t < groups) {
+      stat[t] = ext[(long long)b * 2 * groups + t];
+      stat[groups + t] = rsqrtf(ext[(long long)b * 2 * groups + groups + t] + eps);
+    }
+    __syncthreads();
+  } else {
   if (t < 2 * groups) {
     const float* pb = partial + (long long)b * nchunk * 2 * groups + t;
     float a = 0.f;
@@ -96,8 +116,9 @@ __global__ void gn_apply(const u16* __restrict__ x, long long ldx, u16* __restri
   float mean = 0.f, rstd = 0.f;
   if (t < groups) {
     const float n = (float)HW * (float)cpg;
-    mean = stat[t] / n;
-    const float var = fmaxf(stat[groups + t] / n - mean * mean, 0.f);
+    const float ms = stat[t] / n;                                    // mean of the shifted data
+    const float var = fmaxf(stat[groups + t] / n - ms * ms, 0.f);
+    mean = ms + T::to_f32(x[(long long)b * HW * ldx + t * cpg]);     // + the pivot gn_stats subtracted
     rstd = rsqrtf(var + eps);
   }
   __syncthreads();
@@ -106,6 +127,7 @@ __global__ void gn_apply(const u16* __restrict__ x, long long ldx, u16* __restri
     stat[groups + t] = rstd;
   }
   __syncthreads();
+  }  // own statistics
   const int cv = t % CV, rsub = t / CV;
   float av[8], sv[8];
 #pragma unroll
@@ -329,6 +351,27 @@ __global__ __launch_bounds__(256) void softmax_kernel(u16* __restrict__ x, long 
 
 }  // namespace
 
+namespace {
+// partial sums of gn_stats -> mean / biased variance per (sample, group): [B][mean(groups) | var(groups)]
+template <typename T>
+__global__ void gn_finalize(const u16* __restrict__ x, long long ldx, const float* __restrict__ partial,
+                            float* __restrict__ out, int nchunk, int HW, int C, int groups) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= groups) return;
+  const int cpg = C / groups;
+  const float* pb = partial + (long long)b * nchunk * 2 * groups;
+  float a = 0.f, q = 0.f;
+  for (int k = 0; k < nchunk; ++k) {
+    a += pb[(long long)k * 2 * groups + t];
+    q += pb[(long long)k * 2 * groups + groups + t];
+  }
+  const float n = (float)HW * (float)cpg;
+  const float ms = a / n;
+  out[(long long)b * 2 * groups + t] = ms + T::to_f32(x[(long long)b * HW * ldx + t * cpg]);
+  out[(long long)b * 2 * groups + groups + t] = fmaxf(q / n - ms * ms, 0.f);
+}
+}  // namespace
+
 extern "C" int dbir_groupnorm_nchunk(int HW, int C) {
   (void)C;
   int n = (HW + 15) / 16;
@@ -364,7 +407,8 @@ extern "C" int dbir_groupnorm(int dtype, const void* x, long long ldx, void* y, 
     hipLaunchKernelGGL((gn_stats<TT>), dim3(nchunk, B), dim3(threads), sh1, s, (const u16*)x, ldx, partial, HW, C,  \
                        groups, rows_per_chunk, rpi);                                                               \
     hipLaunchKernelGGL((gn_apply<TT>), dim3(nblk, B), dim3(threads), 0, s, (const u16*)x, ldx, (u16*)y, ldy,       \
-                       partial, gamma, beta, nchunk, HW, C, groups, eps, rows_per_blk, rpi, silu);                  \
+                       partial, gamma, beta, nchunk, HW, C, groups, eps, rows_per_blk, rpi, silu,                  \
+                       (const float*)nullptr);                                                                     \
   } while (0)
   if (dtype == DBIR_F16)
     GN_LAUNCH(F16);
@@ -376,6 +420,76 @@ extern "C" int dbir_groupnorm(int dtype, const void* x, long long ldx, void* y, 
   }
 #undef GN_LAUNCH
   DBIR_CHECK_LAUNCH("dbir_groupnorm");
+  return DBIR_OK;
+}
+
+// Split form for the tiled VAE (reference utils/tilevae/tilevae.py:232-304): statistics of one tile, and normalisation of a
+// tile with statistics aggregated by the caller over all tiles.
+static int gn_geometry(int B, int HW, int C, int groups, int& nchunk, int& rows_per_chunk, int& rpi, int& threads) {
+  nchunk = (512 + B - 1) / B;
+  const int cap = dbir_groupnorm_nchunk(HW, C);
+  if (nchunk > cap) nchunk = cap;
+  rows_per_chunk = (HW + nchunk - 1) / nchunk;
+  nchunk = (HW + rows_per_chunk - 1) / rows_per_chunk;
+  const int CV = C / 8;
+  rpi = CV >= 256 ? 1 : 256 / CV;
+  threads = CV * rpi;
+  return threads <= 1024 && threads >= 2 * groups;
+}
+
+extern "C" int dbir_groupnorm_stats(int dtype, const void* x, long long ldx, int B, int HW, int C, int groups,
+                                    float* workspace, float* mean_var, void* stream) {
+  DBIR_CHECK_ARG(x && workspace && mean_var, "dbir_groupnorm_stats: null pointer");
+  DBIR_CHECK_ARG(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && C <= 4096 && groups <= 64 && B > 0 && B <= 65535,
+                 "dbir_groupnorm_stats: need C%%8==0, C%%groups==0, ld%%8==0, groups<=64 (C=%d)", C);
+  int nchunk, rows_per_chunk, rpi, threads;
+  DBIR_CHECK_ARG(gn_geometry(B, HW, C, groups, nchunk, rows_per_chunk, rpi, threads),
+                 "dbir_groupnorm_stats: unsupported C / groups combination");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t sh1 = (size_t)rpi * 2 * C * sizeof(float);
+  if (dtype == DBIR_F16) {
+    hipLaunchKernelGGL((gn_stats<F16>), dim3(nchunk, B), dim3(threads), sh1, s, (const u16*)x, ldx, workspace, HW, C,
+                       groups, rows_per_chunk, rpi);
+    hipLaunchKernelGGL((gn_finalize<F16>), dim3(B), dim3(64), 0, s, (const u16*)x, ldx, workspace, mean_var, nchunk, HW,
+                       C, groups);
+  } else if (dtype == DBIR_BF16) {
+    hipLaunchKernelGGL((gn_stats<BF16>), dim3(nchunk, B), dim3(threads), sh1, s, (const u16*)x, ldx, workspace, HW, C,
+                       groups, rows_per_chunk, rpi);
+    hipLaunchKernelGGL((gn_finalize<BF16>), dim3(B), dim3(64), 0, s, (const u16*)x, ldx, workspace, mean_var, nchunk, HW,
+                       C, groups);
+  } else {
+    dbir_set_error("dbir_groupnorm_stats: bad dtype");
+    return DBIR_ERR_ARG;
+  }
+  DBIR_CHECK_LAUNCH("dbir_groupnorm_stats");
+  return DBIR_OK;
+}
+
+extern "C" int dbir_groupnorm_apply(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                                    const float* beta, const float* mean_var, int B, int HW, int C, int groups, float eps,
+                                    int silu, void* stream) {
+  DBIR_CHECK_ARG(x && y && gamma && beta && mean_var, "dbir_groupnorm_apply: null pointer");
+  DBIR_CHECK_ARG(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 4096 && groups <= 64 && B > 0 &&
+                     B <= 65535, "dbir_groupnorm_apply: need C%%8==0, C%%groups==0, ld%%8==0, groups<=64 (C=%d)", C);
+  int nchunk, rows_per_chunk, rpi, threads;
+  DBIR_CHECK_ARG(gn_geometry(B, HW, C, groups, nchunk, rows_per_chunk, rpi, threads),
+                 "dbir_groupnorm_apply: unsupported C / groups combination");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int nblk = (1024 + B - 1) / B;
+  int rows_per_blk = (HW + nblk - 1) / nblk;
+  if (rows_per_blk < rpi) rows_per_blk = rpi;
+  nblk = (HW + rows_per_blk - 1) / rows_per_blk;
+  if (dtype == DBIR_F16)
+    hipLaunchKernelGGL((gn_apply<F16>), dim3(nblk, B), dim3(threads), 0, s, (const u16*)x, ldx, (u16*)y, ldy,
+                       (const float*)nullptr, gamma, beta, 0, HW, C, groups, eps, rows_per_blk, rpi, silu, mean_var);
+  else if (dtype == DBIR_BF16)
+    hipLaunchKernelGGL((gn_apply<BF16>), dim3(nblk, B), dim3(threads), 0, s, (const u16*)x, ldx, (u16*)y, ldy,
+                       (const float*)nullptr, gamma, beta, 0, HW, C, groups, eps, rows_per_blk, rpi, silu, mean_var);
+  else {
+    dbir_set_error("dbir_groupnorm_apply: bad dtype");
+    return DBIR_ERR_ARG;
+  }
+  DBIR_CHECK_LAUNCH("dbir_groupnorm_apply");
   return DBIR_OK;
 }
 

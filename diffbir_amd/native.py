@@ -45,6 +45,8 @@ SIGNATURES = {
     "dbir_window_attention": [_I, _P, _LL, _P, _LL, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "dbir_groupnorm_nchunk": [_I, _I],
     "dbir_groupnorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P],
+    "dbir_groupnorm_stats": [_I, _P, _LL, _I, _I, _I, _I, _P, _P, _P],
+    "dbir_groupnorm_apply": [_I, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dbir_layernorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _F, _P],
     "dbir_softmax_rows": [_I, _P, _LL, _LL, _I, _P],
     "dbir_add_scaled": [_I, _P, _LL, _P, _LL, _F, _P, _LL, _LL, _I, _P],

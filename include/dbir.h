@@ -36,8 +36,8 @@ extern "C" {
 
 const char* dbir_last_error(void);
 int dbir_abi_version(void);
-/* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 1 = synchronous-staging
- * attention kernel, 2 (default) = double-buffered kernel with the folded-scale softmax. */
+/* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 2 (default) = LDS-resident
+ * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape. */
 #define DBIR_OPT_ATTN_VARIANT 1
 int dbir_set_option(int key, int value);
 
@@ -142,6 +142,14 @@ int dbir_groupnorm_nchunk(int HW, int C);
 int dbir_groupnorm(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,
                    const float* beta, int B, int HW, int C, int groups, float eps, int silu, float* workspace,
                    void* stream);
+/* Split form (tiled VAE, reference utils/tilevae/tilevae.py:232-304: GroupNorm statistics aggregated over the tiles of an
+ * image): dbir_groupnorm_stats -> mean_var f32 [B][mean(groups) | biased var(groups)] of one tile (same workspace
+ * contract as dbir_groupnorm); dbir_groupnorm_apply normalises with caller-supplied statistics of that layout. */
+int dbir_groupnorm_stats(int dtype, const void* x, long long ldx, int B, int HW, int C, int groups, float* workspace,
+                         float* mean_var, void* stream);
+int dbir_groupnorm_apply(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                         const float* beta, const float* mean_var, int B, int HW, int C, int groups, float eps, int silu,
+                         void* stream);
 /* dbir_layernorm: nn.LayerNorm rows (attention.py:255-257; swinir.py:205,211,764), eps 1e-5.
  * Normalises over the first C columns; columns [C, Cpad) of y are written as zero. */
 int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,

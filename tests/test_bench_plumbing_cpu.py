@@ -42,3 +42,14 @@ def test_two_ranks_as_launched_by_the_driver():
     # rank 1 sleeps 40 ms per step, rank 0 20 ms: the reported step time is the slowest rank's
     assert r["ms_per_step"] >= 39.0, r["ms_per_step"]
     assert abs(r["value"] - 8 * 4 * 2 / (r["ms_per_step"] * 4e-3)) < 1e-6 * r["value"]
+
+
+def test_gpus_flag_self_spawns_and_checks_world_size():
+    """`python bench.py --gpus 2` without a launcher re-launches itself under torch.distributed.run (one rank per GPU);
+    the two-rank selftest also runs the bucketed weight broadcast and the gather of the per-rank batches to rank 0."""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--selftest"])
+    assert r["n_gpus"] == 2 and r.get("broadcast_checked") is True and r["gathered_batch"][0] == 16
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--selftest"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

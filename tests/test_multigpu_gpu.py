@@ -1,0 +1,55 @@
+"""-m gpu, needs >= 2 GPUs (skips on the 1-GPU box): bench.py exactly as the driver launches it for N = 2 — one rank per GPU
+over RCCL — exercising what the N = 1 run cannot: the bucketed RCCL weight broadcast (`parallel.broadcast_state_dict`), batch
+sharding with the gather of the restored uint8 batches to rank 0 (`parallel.gather_batch`), and tile sharding with one RCCL
+all-reduce per network evaluation (`parallel.enable_tile_sharding`).  The same plumbing runs on CPU / gloo in
+tests/test_bench_plumbing_cpu.py and tests/test_parallel_cpu.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+           "--no-roofline"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_two_ranks_batch_sharded_over_rccl():
+    r = _run(["--sampler-steps", "2", "--batch", "2"])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"
+    assert r["gathered_batch"] == [4, 512, 512, 3] and "broadcast_state_dict" in r["weights"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_two_ranks_tile_sharded_over_rccl():
+    r = _run(["--config", "c4", "--sampler-steps", "2"])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "tile-shard2" and r["scaling"] == "strong"
+
+
+def test_gpus_flag_must_match_world_size():
+    """`--gpus N` with a different WORLD_SIZE is an error, not a silent 1-GPU benchmark."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--selftest"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

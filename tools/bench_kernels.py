@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--tiles", default="1,5,6,7")
     ap.add_argument("--only", default="")
-    ap.add_argument("--attn-variants", default="2", help="comma list of attention kernel variants to time")
+    ap.add_argument("--attn-variants", default="2,3", help="comma list of attention kernel variants to time")
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(",")]
     rows = []
@@ -104,7 +104,7 @@ def main():
             del x, out, pw
     if want("attn"):
         for (b, hds, lq, lk) in [(B, 5, 4096, 4096), (B, 10, 1024, 1024), (B, 20, 256, 256), (B, 5, 4096, 77),
-                                 (B, 10, 1024, 77)]:
+                                 (B, 10, 1024, 77), (B, 20, 256, 77), (B, 20, 64, 77)]:
             C = hds * 64
             q, k = rnd(b, lq, C), rnd(b, lk, C)
             lkp = (lk + 7) // 8 * 8
