@@ -85,25 +85,23 @@ class ControlLDM:
 
     # ---- VAE / conditioning ---------------------------------------------------------------------
     def vae_encode(self, image: T, sample: bool = True, tiled: bool = False, tile_size: int = -1) -> T:
-        if tiled:
-            raise NotImplementedError("tiled VAE (VAEHook) is out of scope of this engine: 288 GB HBM3E holds the "
-                                      "untiled activations; see DESIGN.md")
+        """reference cldm.py:92-119; `tiled` = the reference's VAEHook algorithm (model/vae.py encode_moments_tiled)."""
         if sample:
             raise NotImplementedError("posterior sampling is a training-only path; inference uses sample=False")
-        return self.vae.encode_mode(image, self.scale_factor)
+        return self.vae.encode_mode(image, self.scale_factor, tile_size=tile_size if tiled else 0)
 
     def vae_decode(self, z: T, tiled: bool = False, tile_size: int = -1) -> T:
+        """reference cldm.py:121-141."""
         if tiled:
-            raise NotImplementedError("tiled VAE (VAEHook) is out of scope of this engine; see DESIGN.md")
+            return self.vae.decode_tiled(z, tile_size, in_scale=1.0 / self.scale_factor)
         return self.vae.decode(z, in_scale=1.0 / self.scale_factor)
 
     def prepare_condition(self, cond_img: T, txt: List[str], tiled: bool = False, tile_size: int = -1) -> Dict[str, T]:
         """reference cldm.py:143-158: c_img = mode(encoder(img*2-1)) * scale_factor (the `*2-1` is fused into the
         layout-conversion kernel)."""
-        if tiled:
-            raise NotImplementedError("tiled VAE (VAEHook) is out of scope of this engine; see DESIGN.md")
         return dict(c_txt=self.clip.encode(txt),
-                    c_img=self.vae.encode_mode(cond_img, self.scale_factor, in_scale=2.0, in_shift=-1.0))
+                    c_img=self.vae.encode_mode(cond_img, self.scale_factor, in_scale=2.0, in_shift=-1.0,
+                                               tile_size=tile_size if tiled else 0))
 
     # ---- network evaluation ---------------------------------------------------------------------
     def forward(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:

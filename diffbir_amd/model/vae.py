@@ -7,7 +7,8 @@ GEMMs (Q K^T, P V) around a row-softmax kernel, over QUERY CHUNKS of at most `AT
 attention (every query row sees all keys), but never an [L, L] matrix — L = 4096 at 512x512 is one chunk, L = 262144
 at 4096x4096 (137 GB of scores if materialised) runs in 4 GB pieces.
 """
-from typing import Optional
+import math
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -105,10 +106,14 @@ class AutoencoderKL(NativeModule):
         return ops.conv3x3(h, r.conv2, residual=skip)
 
     def _run_attn(self, a: dict, x: T) -> T:
+        return self._attn_core(a, ops.groupnorm(x, a["gn"][0], a["gn"][1], 1e-6, False), x)
+
+    def _attn_core(self, a: dict, hn: T, x: T) -> T:
+        """single-head attention on the normalised input `hn`, residual `x` (vae.py:253-282)."""
         B, H, W, C = x.shape
         L = H * W
         Lp = (L + 63) // 64 * 64
-        hn = ops.groupnorm(x, a["gn"][0], a["gn"][1], 1e-6, False).reshape(B * L, C)
+        hn = hn.reshape(B * L, C)
         qk = ops.linear(hn, a["qk"]).reshape(B, L, 2 * C)
         vt = torch.zeros((B, C, Lp), dtype=x.dtype, device=x.device) if Lp != L else \
             torch.empty((B, C, Lp), dtype=x.dtype, device=x.device)
@@ -123,6 +128,129 @@ class AutoencoderKL(NativeModule):
             ops.softmax_rows_(sc, L)
             ops.bmm_nt(sc, vt, o[:, q0:q0 + n])
         return ops.linear(o.reshape(B, H, W, C), a["proj"], residual=x)
+
+    # ------------------------------------------------------------------ tiled execution (reference utils/tilevae/tilevae.py)
+    # The reference's VAEHook (non-fast mode, what cldm.py:99-111,127-138 selects) cuts the input into tiles padded by
+    # 32 px (encoder) / 11 latent px (decoder), runs the network tile by tile, and keeps the result close to the untiled
+    # one by sharing GroupNorm statistics: at every GroupNorm all tiles stop, their per-(sample, group) mean and variance
+    # are averaged with weights proportional to the tile's pixel count, and every tile is normalised with the averages.
+    # Convolutions see each tile's own zero padding (the padded ring is cropped away at the end) and the mid-block
+    # attention runs inside each tile.  The engine reproduces exactly that layer-synchronous algorithm: every layer is
+    # applied to all tiles before the next one (same result as the reference's task-queue zig-zag, which only orders
+    # host <-> device traffic), so its output tracks the reference's TILED output, not the untiled one.
+    @staticmethod
+    def _best_tile_size(lower: int, upper: int) -> int:
+        """tilevae.py:325-338: the smallest size >= lower that is a multiple of 32 / 16 / ... / 2 and <= upper."""
+        div = 32
+        while div >= 2:
+            rem = lower % div
+            if rem == 0:
+                return lower
+            cand = lower - rem + div
+            if cand <= upper:
+                return cand
+            div //= 2
+        return lower
+
+    @classmethod
+    def split_tiles(cls, h: int, w: int, tile_size: int, pad: int, is_decoder: bool):
+        """tilevae.py:340-398 -> (input boxes, output boxes), boxes = [x1, x2, y1, y2]."""
+        nh = max(math.ceil((h - 2 * pad) / tile_size), 1)
+        nw = max(math.ceil((w - 2 * pad) / tile_size), 1)
+        th = cls._best_tile_size(math.ceil((h - 2 * pad) / nh), tile_size)
+        tw = cls._best_tile_size(math.ceil((w - 2 * pad) / nw), tile_size)
+        ins, outs = [], []
+        for i in range(nh):
+            for j in range(nw):
+                box = [pad + j * tw, min(pad + (j + 1) * tw, w), pad + i * th, min(pad + (i + 1) * th, h)]
+                ob = [box[0] if box[0] > pad else 0, box[1] if box[1] < w - pad else w,
+                      box[2] if box[2] > pad else 0, box[3] if box[3] < h - pad else h]
+                outs.append([v * 8 if is_decoder else v // 8 for v in ob])
+                ins.append([max(0, box[0] - pad), min(w, box[1] + pad), max(0, box[2] - pad), min(h, box[3] + pad)])
+        return ins, outs
+
+    def _gn_tiles(self, tiles: List[T], gn, silu: bool) -> List[T]:
+        """GroupNorm over a list of tiles with pixel-weighted averaged statistics (tilevae.py:241-279)."""
+        if len(tiles) == 1:
+            return [ops.groupnorm(tiles[0], gn[0], gn[1], 1e-6, silu)]
+        stats = [ops.groupnorm_stats(t) for t in tiles]
+        px = torch.tensor([t.shape[1] * t.shape[2] for t in tiles], dtype=torch.float32, device=tiles[0].device)
+        wgt = px / px.max()
+        wgt = wgt / wgt.sum()
+        mv = (torch.stack(stats, dim=0) * wgt[:, None, None]).sum(dim=0).contiguous()
+        return [ops.groupnorm_apply(t, gn[0], gn[1], mv, 1e-6, silu) for t in tiles]
+
+    def _res_tiles(self, r: _VRes, tiles: List[T]) -> List[T]:
+        h = self._gn_tiles(tiles, r.gn1, True)
+        h = [ops.conv3x3(t, r.conv1) for t in h]
+        h = self._gn_tiles(h, r.gn2, True)
+        skip = tiles if r.nin is None else [ops.linear(t, r.nin) for t in tiles]
+        return [ops.conv3x3(t, r.conv2, residual=sk) for t, sk in zip(h, skip)]
+
+    def _attn_tiles(self, a: dict, tiles: List[T]) -> List[T]:
+        hn = self._gn_tiles(tiles, a["gn"], False)
+        return [self._attn_core(a, n, x) for n, x in zip(hn, tiles)]
+
+    def _paste(self, tiles: List[T], ins, outs, is_decoder: bool, B: int, H: int, W: int) -> T:
+        """crop_valid_region + write into the result (tilevae.py:218-229, 545-547); NHWC."""
+        res = torch.zeros((B, H, W, tiles[0].shape[-1]), dtype=tiles[0].dtype, device=tiles[0].device)
+        for t, ib, ob in zip(tiles, ins, outs):
+            pb = [v * 8 if is_decoder else v // 8 for v in ib]
+            m = [ob[k] - pb[k] for k in range(4)]
+            res[:, ob[2]:ob[3], ob[0]:ob[1]] = t[:, m[2]:t.shape[1] + m[3], m[0]:t.shape[2] + m[1]]
+        return res
+
+    def encode_moments_tiled(self, x: T, tile_size: int, in_scale: float = 1.0, in_shift: float = 0.0) -> T:
+        """Tiled encoder -> moments NHWC f32 (VAEHook(encoder) then quant_conv, cldm.py:99-111)."""
+        self._ensure_packed()
+        B, _, H, W = x.shape
+        pad = 32
+        if max(H, W) <= pad * 2 + tile_size:
+            print("[Tiled VAE]: the input size is tiny and unnecessary to tile.")
+            return self.encode_moments(x, in_scale, in_shift)
+        ins, outs = self.split_tiles(H, W, tile_size, pad, False)
+        x = x.float()
+        t = [ops.nchw_to_nhwc(x[:, :, b[2]:b[3], b[0]:b[1]].contiguous(), None, 8, self._dtype, in_scale, in_shift)
+             for b in ins]
+        t = [ops.conv3x3(v, self.e_conv_in) for v in t]
+        for blocks, ds in self.e_down:
+            for r in blocks:
+                t = self._res_tiles(r, t)
+            if ds is not None:
+                t = [ops.conv3x3(v, ds, stride=2, pad=0, out_hw=(v.shape[1] // 2, v.shape[2] // 2)) for v in t]
+        t = self._res_tiles(self.e_mid[0], t)
+        t = self._attn_tiles(self.e_mid[1], t)
+        t = self._res_tiles(self.e_mid[2], t)
+        t = self._gn_tiles(t, self.e_norm_out, True)
+        t = [ops.conv3x3(v, self.e_conv_out) for v in t]
+        h = self._paste(t, ins, outs, False, B, H // 8, W // 8)
+        return ops.linear(h, self.quant, out_f32=True)
+
+    def decode_tiled(self, z: T, tile_size: int, in_scale: float = 1.0) -> T:
+        """post_quant_conv then the tiled decoder (cldm.py:127-138); tile_size in latent pixels."""
+        self._ensure_packed()
+        B, _, H, W = z.shape
+        pad = 11
+        if max(H, W) <= pad * 2 + tile_size:
+            print("[Tiled VAE]: the input size is tiny and unnecessary to tile.")
+            return self.decode(z, in_scale=in_scale)
+        h = ops.nchw_to_nhwc(z.float().contiguous(), None, 8, self._dtype, in_scale, 0.0)
+        h = ops.linear(h, self.post_quant)
+        ins, outs = self.split_tiles(H, W, tile_size, pad, True)
+        t = [h[:, b[2]:b[3], b[0]:b[1]].contiguous() for b in ins]
+        t = [ops.conv3x3(v, self.d_conv_in) for v in t]
+        t = self._res_tiles(self.d_mid[0], t)
+        t = self._attn_tiles(self.d_mid[1], t)
+        t = self._res_tiles(self.d_mid[2], t)
+        for blocks, us in self.d_up:
+            for r in blocks:
+                t = self._res_tiles(r, t)
+            if us is not None:
+                t = [ops.conv3x3(v, us, upsample=True) for v in t]
+        t = self._gn_tiles(t, self.d_norm_out, True)
+        t = [ops.conv3x3(v, self.d_conv_out, out_f32=True) for v in t]
+        o = self._paste(t, ins, outs, True, B, H * 8, W * 8)
+        return ops.nhwc_to_nchw(o, self.out_ch)
 
     # ------------------------------------------------------------------ API
     def encode_moments(self, x: T, in_scale: float = 1.0, in_shift: float = 0.0) -> T:
@@ -142,9 +270,12 @@ class AutoencoderKL(NativeModule):
         h = ops.conv3x3(h, self.e_conv_out)
         return ops.linear(h, self.quant, out_f32=True)
 
-    def encode_mode(self, x: T, scale_factor: float, in_scale: float = 1.0, in_shift: float = 0.0) -> T:
-        """mode() of the diagonal Gaussian = mean = first z_channels of the moments, times scale_factor."""
-        m = self.encode_moments(x, in_scale, in_shift)
+    def encode_mode(self, x: T, scale_factor: float, in_scale: float = 1.0, in_shift: float = 0.0,
+                    tile_size: int = 0) -> T:
+        """mode() of the diagonal Gaussian = mean = first z_channels of the moments, times scale_factor.
+        tile_size > 0: the reference's tiled encoder."""
+        m = (self.encode_moments_tiled(x, tile_size, in_scale, in_shift) if tile_size > 0
+             else self.encode_moments(x, in_scale, in_shift))
         return ops.nhwc_to_nchw(m, self.z_channels, scale=scale_factor)
 
     def decode(self, z: T, in_scale: float = 1.0, out_scale: float = 1.0, out_shift: Optional[T] = None) -> T:

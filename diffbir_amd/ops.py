@@ -365,6 +365,34 @@ def groupnorm(x: T, gamma: T, beta: T, eps: float, silu: bool, out: Optional[T] 
     return out
 
 
+def groupnorm_stats(x: T, groups: int = 32) -> T:
+    """Per-sample GroupNorm statistics of x [B, H, W, C]: f32 [B, 2*groups] = mean(groups) | biased variance(groups)."""
+    _gpu(x)
+    B, C = x.shape[0], x.shape[-1]
+    HW = _rows(x) // B
+    nchunk = native.lib().dbir_groupnorm_nchunk(HW, C)
+    ws = torch.empty(B * (2 * C * nchunk + 2 * C), dtype=torch.float32, device=x.device)
+    mv = torch.empty((B, 2 * groups), dtype=torch.float32, device=x.device)
+    native.check(native.lib().dbir_groupnorm_stats(_dt(x), x.data_ptr(), _ld(x), B, HW, C, groups, ws.data_ptr(),
+                                                   mv.data_ptr(), _stream()), "dbir_groupnorm_stats")
+    return mv
+
+
+def groupnorm_apply(x: T, gamma: T, beta: T, mean_var: T, eps: float, silu: bool, out: Optional[T] = None,
+                    groups: int = 32) -> T:
+    """GroupNorm(+SiLU) of x with caller-supplied statistics `mean_var` f32 [B, 2*groups] (tiled VAE)."""
+    _gpu(x, gamma, beta, mean_var, out)
+    B, C = x.shape[0], x.shape[-1]
+    HW = _rows(x) // B
+    assert mean_var.dtype == torch.float32 and mean_var.is_contiguous() and tuple(mean_var.shape) == (B, 2 * groups)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    native.check(native.lib().dbir_groupnorm_apply(_dt(x), x.data_ptr(), _ld(x), out.data_ptr(), _ld(out),
+                                                   gamma.data_ptr(), beta.data_ptr(), mean_var.data_ptr(), B, HW, C,
+                                                   groups, eps, int(silu), _stream()), "dbir_groupnorm_apply")
+    return out
+
+
 def layernorm(x: T, gamma: T, beta: T, C: Optional[int] = None, eps: float = 1e-5, out: Optional[T] = None) -> T:
     """Row LayerNorm over the first C columns of x [..., Cpad]; pad columns of the output are zero."""
     _gpu(x, gamma, beta, out)

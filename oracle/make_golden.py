@@ -168,6 +168,42 @@ def gen_full_configs(R, only=None):
         print(name, out.shape, f"{dt:.1f} s", flush=True)
 
 
+@torch.no_grad()
+def gen_tiled_vae(R):
+    """Tiled VAE: the reference's VAEHook through ControlLDM.vae_encode / vae_decode with `tiled=True`
+    (cldm.py:99-111,127-138) on the tiny config, edge tiles included, + its tile geometry for several sizes."""
+    import importlib
+    import json
+    from diffbir_amd import configs
+    tv = importlib.import_module("diffbir.utils.tilevae.tilevae")
+    cldm, swin, diff, W = build_reference(R, "tiny", configs.get("DIFFUSION_V21"))
+    x = torch.tensor(cases.make_lq(31, 1, 608, 712)).float().div(255).permute(0, 3, 1, 2).contiguous()
+    g = {}
+    with cases.quiet():
+        g["enc_tiled_256"] = cldm.vae_encode(x * 2 - 1, sample=False, tiled=True, tile_size=256).numpy()
+        z = cases.NoiseStream(9)((1, 4, 76, 89))
+        g["dec_tiled_32"] = cldm.vae_decode(z, tiled=True, tile_size=32).numpy()
+        x2 = torch.tensor(cases.make_lq(32, 2, 384, 320)).float().div(255).permute(0, 3, 1, 2).contiguous()
+        g["enc_tiled_b2_128"] = cldm.vae_encode(x2 * 2 - 1, sample=False, tiled=True, tile_size=128).numpy()
+        # whole pipeline with --vae_encoder_tiled --vae_decoder_tiled (tile sizes 256 / 256), 3 spaced steps
+        pipe = R.SwinIRPipeline(swin, cldm, diff, None, "cpu")
+        torch.manual_seed(5)
+        g["pipe_vae_tiled"] = pipe.run(cases.make_lq(9, 1, 600, 712), 3, 1.0, False, 512, 256, True, 256, True, 256, False, 512,
+                                       256, "", cases.NEG_PROMPT, 4.0, "noise", "spaced", 0, False, 0, 0, 300, 1, 1, 1)
+    np.savez_compressed(os.path.join(OUT, "tiny_tiled_vae.npz"), **g)
+    geo = {}
+    for (h, w, ts, dec) in ((608, 712, 256, False), (76, 89, 32, True), (2048, 2048, 256, False), (256, 256, 32, True),
+                            (384, 320, 128, False), (600, 200, 256, False), (512, 512, 64, True), (97, 131, 32, True)):
+        hook = tv.VAEHook(None, ts, dec, False, False, False)
+        with cases.quiet():
+            ins, outs = hook.split_tiles(h, w)
+        geo[f"{h}x{w}_{ts}_{'dec' if dec else 'enc'}"] = dict(ins=[list(map(int, b)) for b in ins],
+                                                                outs=[list(map(int, b)) for b in outs])
+    with open(os.path.join(OUT, "tiled_vae_geometry.json"), "w") as f:
+        json.dump(geo, f)
+    print("tiled vae done", {k: v.shape for k, v in g.items()}, len(geo))
+
+
 TOKENIZER_PROMPTS = [
     "", "low quality, blurry, low-resolution, noisy, unsharp, weird textures", "a photo of a cat",
     "Cinematic, High Contrast, highly detailed, taken using a Canon EOS R camera, hyper detailed photo - realistic "
@@ -375,6 +411,8 @@ if __name__ == "__main__":
         gen_modules(R, "full", "full", 256, configs.get("DIFFUSION_V21"))
     elif what == "full_pipeline":
         gen_full_pipeline(R)
+    elif what == "tiled_vae":
+        gen_tiled_vae(R)
     elif what == "samplers":
         gen_samplers(R)
     elif what == "ref_lowp":

@@ -170,6 +170,29 @@ def groupnorm(x, gamma, beta, eps, silu, out=None, groups=32):
     return out
 
 
+def groupnorm_stats(x, groups=32):
+    B, C = x.shape[0], x.shape[-1]
+    xf = x.float().reshape(B, -1, groups, C // groups)
+    var, mean = torch.var_mean(xf, dim=(1, 3), unbiased=False)
+    return torch.cat([mean, var], dim=1).contiguous()
+
+
+def groupnorm_apply(x, gamma, beta, mean_var, eps, silu, out=None, groups=32):
+    B, C = x.shape[0], x.shape[-1]
+    cpg = C // groups
+    mean = mean_var[:, :groups].repeat_interleave(cpg, dim=1)
+    var = mean_var[:, groups:].repeat_interleave(cpg, dim=1)
+    shp = (B,) + (1,) * (x.dim() - 2) + (C,)
+    y = (x.float() - mean.reshape(shp)) * torch.rsqrt(var.reshape(shp) + eps) * gamma.float() + beta.float()
+    if silu:
+        y = F.silu(y)
+    y = y.to(x.dtype)
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
 def layernorm(x, gamma, beta, C=None, eps=1e-5, out=None):
     Cpad = x.shape[-1]
     C = Cpad if C is None else C
@@ -294,7 +317,8 @@ def f32_nchw_to_u8_nhwc(src):
     return (src * 255.0).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
 
 
-_NAMES = ["linear", "linear_t", "conv3x3", "bmm_nt", "attention", "window_attention", "groupnorm", "layernorm",
+_NAMES = ["linear", "linear_t", "conv3x3", "bmm_nt", "attention", "window_attention", "groupnorm", "groupnorm_stats",
+          "groupnorm_apply", "layernorm",
           "softmax_rows_", "add_scaled", "nchw_to_nhwc", "nhwc_to_nchw", "pixel_unshuffle", "timestep_embedding",
           "lincomb4", "spaced_step", "tile_gather", "tile_accumulate", "tile_accumulate_partial", "tile_normalize",
           "u8_to_f32_nchw", "wavelet_blur", "colorfix",

@@ -34,9 +34,9 @@ def build_engine(cfg_name: str, diffusion_cfg: str, device, dtype, W=None, raw_d
 
 
 def run_pipe(pipe, lq, steps, sampler, seed, cfg=4.0, tiled=False, tile=512, stride=256, cleaner_tiled=False,
-             strength=1.0, start="noise", noise_aug=0, rescale_cfg=False):
+             strength=1.0, start="noise", noise_aug=0, rescale_cfg=False, vae_tiled=False):
     pipe.randn = cases.NoiseStream(seed)
-    return pipe.run(lq, steps, strength, cleaner_tiled, 512, 256, False, 256, False, 256, tiled, tile, stride,
+    return pipe.run(lq, steps, strength, cleaner_tiled, 512, 256, vae_tiled, 256, vae_tiled, 256, tiled, tile, stride,
                     "", cases.NEG_PROMPT, cfg, start, sampler, noise_aug, rescale_cfg, 0, 0, 300, 1, 1, 1)
 
 

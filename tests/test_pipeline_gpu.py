@@ -242,3 +242,26 @@ def test_vae_attention_query_chunking_is_exact():
             assert torch.equal(cldm.vae.encode_mode(x, 0.18215, 2.0, -1.0), full_e)
         finally:
             vae_mod.ATTN_CHUNK_BYTES = old
+
+
+@torch.no_grad()
+def test_tiled_vae_vs_reference_golden(golden_dir):
+    """SURVEY.md §8f N1 on the HIP kernels: the reference's tiled VAE (VAEHook: pixel-weighted GroupNorm statistics over
+    padded tiles, per-tile attention) through vae_encode / vae_decode(tiled=True) and through Pipeline.run's flags."""
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    g = np.load(os.path.join(golden_dir, "tiny_tiled_vae.npz"))
+    x = torch.tensor(cases.make_lq(31, 1, 608, 712)).float().div(255).permute(0, 3, 1, 2).contiguous().to(dev)
+    res = {"enc_tiled_256": rel_err(cldm.vae_encode(x * 2 - 1, sample=False, tiled=True, tile_size=256), g["enc_tiled_256"])}
+    z = cases.NoiseStream(9)((1, 4, 76, 89)).to(dev)
+    res["dec_tiled_32"] = rel_err(cldm.vae_decode(z, tiled=True, tile_size=32), g["dec_tiled_32"])
+    x2 = torch.tensor(cases.make_lq(32, 2, 384, 320)).float().div(255).permute(0, 3, 1, 2).contiguous().to(dev)
+    res["enc_tiled_b2_128"] = rel_err(cldm.vae_encode(x2 * 2 - 1, sample=False, tiled=True, tile_size=128),
+                                      g["enc_tiled_b2_128"])
+    REPORT["tiled_vae_tiny_fp16"] = {k: v[0] for k, v in res.items()}
+    print({k: f"{v[0]:.2e}" for k, v in res.items()})
+    assert all(v[0] < MOD_TOL[torch.float16] for v in res.values()), res
+    out = run_pipe(pipe, cases.make_lq(9, 1, 600, 712), 3, "spaced", 5, vae_tiled=True)
+    psnr = cases.psnr_u8(out, g["pipe_vae_tiled"])
+    REPORT["tiny_pipe_vae_tiled_fp16"] = psnr
+    assert psnr >= 45.0, psnr
