@@ -354,6 +354,8 @@ def main():
         "vs_baseline_note": "BASELINE.json `published` is empty: the reference publishes no throughput numbers",
     }
     res.update(extra)
+    if not args.selftest:
+        res["peak_mem_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
     if args.selftest:
         res["data"] = "SELFTEST (fake workload, CPU/gloo) - not a measurement"
     if rank == 0 and not args.no_roofline and not args.selftest:
