@@ -274,6 +274,9 @@ int dbir_gemm_glds(const dbir_gemm_desc& d, int Hv, int Wv, int tile, hipStream_
 // halo-patch 3x3 convolution kernel (gemm_halo.hip), tiles 50 / 51
 bool dbir_gemm_halo_eligible(const dbir_gemm_desc& d, int tile);
 int dbir_gemm_halo(const dbir_gemm_desc& d, int tile, hipStream_t s);
+// persistent small-K linear kernel (gemm_pers.hip), tiles 70 - 73
+bool dbir_gemm_pers_eligible(const dbir_gemm_desc& d, int tile);
+int dbir_gemm_pers(const dbir_gemm_desc& d, int tile, hipStream_t s);
 
 extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   DBIR_CHECK_ARG(dd && dd->A && dd->W && dd->C, "dbir_gemm: null pointer");
@@ -303,7 +306,14 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 69 && tile != 13, "dbir_gemm: bad tile %d", tile);
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 79 && tile != 13, "dbir_gemm: bad tile %d", tile);
+  if (tile >= 70) {
+    DBIR_CHECK_ARG(dbir_gemm_pers_eligible(d, tile),
+                   "dbir_gemm: tile %d (persistent linear kernel) needs a dense linear with K %% 32 == 0, M a multiple of "
+                   "the tile height, N %% 8 == 0, a 16-byte aligned 16-bit row-major output / residual and no row vector, "
+                   "split-K, transposed or f32 store", tile);
+    return dbir_gemm_pers(d, tile, reinterpret_cast<hipStream_t>(stream));
+  }
   if (tile == 0 || tile >= 5) {
     const bool ok = dbir_gemm_glds_eligible(d);
     DBIR_CHECK_ARG(ok || tile == 0, "dbir_gemm: tile %d (direct-to-LDS kernel) needs K/Cin %% 64 == 0, 16-byte aligned "

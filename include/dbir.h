@@ -96,7 +96,12 @@ typedef struct dbir_gemm_desc {
                50 / 51: halo-patch 3x3 convolution kernel (gemm_halo.hip), 256x160 / 256x128 — stride-1 pad-1 convs whose
                256-row tiles are whole image rows (Wo a power of two <= 64): one LDS-resident activation patch per
                64-channel slice serves all 9 taps; split-K slices the channel slices; 52 / 53: the same tiles in lockstep with
-               cross-tile fragment prefetch; 54: 256x32 for f32 heads */
+               cross-tile fragment prefetch; 54: 256x32 for f32 heads;
+               70 - 73: persistent linear kernel (gemm_pers.hip) for the small-K projections — workgroups walk several
+               output tiles, the K tiles of all of them form one flat stream through the LDS ring, barrier-free
+               register epilogue: 256x160 / 128x160 (two workgroups per CU) / 256x128 / 128x128 (two per CU); dense
+               linear with K % 32 == 0, M a multiple of the tile height, N % 8 == 0, no row vector / split-K /
+               transposed or f32 store */
   /* split-K (direct-to-LDS tiles >= 5 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
    * into f32 partial sums in `ws` (>= splitk * batch * M * N * 4 bytes, 16-byte aligned, caller-owned), then a second
    * kernel sums the slices in a fixed order and applies the epilogue.  For small-M / huge-K problems (8x8 and 16x16

@@ -480,6 +480,101 @@ def test_halo_rejects_ineligible(tile):
         ops.linear(x, pl, tile=tile)
 
 
+# ------------------------------------------------------------------------------------------------ persistent linear kernel
+PERS_TILES = [70, 71, 72, 73]   # 256x160 / 128x160 (two workgroups per CU) / 256x128 / 128x128 (two per CU)
+PERS_CASES = [
+    # M, N, K: one tile per workgroup, several tiles per workgroup (flat K stream across tile boundaries), ragged N
+    (256, 320, 320), (1024, 640, 64), (2048, 1280, 1280), (65536, 320, 320), (32768, 640, 320), (16384, 1288, 128),
+    (4096, 8, 64), (8192, 200, 2560),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", PERS_TILES)
+@pytest.mark.parametrize("M,N,K", PERS_CASES)
+def test_pers_linear(M, N, K, tile, dtype):
+    """Persistent linear kernel (gemm_pers.hip): independent f32 statement, the default kernel (the bias enters the f32
+    accumulation first instead of last: agreement within an ulp of the 16-bit output, not bit-identity), and run-to-run
+    bit-identity (race screen for the counted-vmcnt flat stream and the barrier-free epilogue)."""
+    x = rnd(M, K, dtype=dtype)
+    w, b = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    got = ops.linear(x, pw, tile=tile)
+    ref = (x.float() @ w.to(dtype).float().t() + b).to(dtype)
+    check(f"pers linear {M}x{N}x{K} t{tile}", got, ref, dtype)
+    base = ops.linear(x, pw, tile=5).float()
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    # (+ an absolute term for cancelling sums: the f32 accumulation order differs, sqrt(K) * 2^-24 * |terms|)
+    assert ((got.float() - base).abs() <= ulp * base.abs() + 3e-5).all(), "more than one 16-bit ulp from tile 5"
+    for it in range(4):
+        assert torch.equal(ops.linear(x, pw, tile=tile), got), f"tile {tile} not reproducible (iteration {it})"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", PERS_TILES)
+@pytest.mark.parametrize("act", [emu.ACT_NONE, emu.ACT_SILU, emu.ACT_GELU, emu.ACT_LRELU])
+def test_pers_linear_epilogue(act, tile, dtype):
+    M, N, K = 1536, 200, 192
+    x = rnd(M, K + 24, dtype=dtype)[:, :K]                             # strided A (ld > K)
+    w, b = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    res = rnd(M, N + 8, dtype=dtype, seed=3)[:, :N]                    # strided residual
+    out_a = torch.zeros(M, N + 40, dtype=dtype, device=DEV)
+    out_b = torch.zeros(M, N + 40, dtype=dtype, device=DEV)
+    kw = dict(act=act, act_param=0.2, out_scale=0.7, residual=res)
+    ops.linear(x, pw, out=out_a[:, 16:16 + N], tile=tile, **kw)
+    emu.linear(x, pw, out=out_b[:, 16:16 + N], **kw)
+    check(f"pers linear epilogue act{act} t{tile}", out_a, out_b, dtype, scale=1.5)  # also: nothing outside the view
+    # no bias; residual == output (in place), as the transformer blocks call it
+    pw0 = ops.pack_linear(w.cpu(), None, dtype, DEV)
+    h_a, h_b = res.contiguous().clone(), res.contiguous().clone()
+    ops.linear(x, pw0, out=h_a, residual=h_a, tile=tile)
+    emu.linear(x, pw0, out=h_b, residual=h_b)
+    check(f"pers linear in-place residual t{tile}", h_a, h_b, dtype, scale=1.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", PERS_TILES)
+@pytest.mark.parametrize("M,Nh,K", [(512, 1280, 320), (16384, 320, 320), (256, 64, 64)])
+def test_pers_geglu(M, Nh, K, tile, dtype):
+    x = rnd(M, K, dtype=dtype)
+    w, b = rnd(2 * Nh, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(2 * Nh, dtype=torch.float32, seed=2)
+    pw = ops.pack_geglu(w.cpu(), b.cpu(), dtype, DEV)
+    if tile in (70, 71):   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
+        with pytest.raises(Exception):
+            ops.linear(x, pw, tile=tile)
+        return
+    h = x.float() @ w.to(dtype).float().t() + b
+    ref = (h[:, :Nh] * torch.nn.functional.gelu(h[:, Nh:])).to(dtype)
+    got = ops.linear(x, pw, tile=tile)
+    check(f"pers geglu {M}x{Nh}x{K} t{tile}", got, ref, dtype)
+    res = rnd(M, Nh, dtype=dtype, seed=5)
+    check("pers geglu+res", ops.linear(x, pw, residual=res, tile=tile), emu.linear(x, pw, residual=res), dtype, 1.5)
+    assert torch.equal(ops.linear(x, pw, tile=tile), got)
+
+
+@pytest.mark.parametrize("tile", PERS_TILES)
+def test_pers_rejects_ineligible(tile):
+    """anything the persistent kernel cannot run must be refused loudly (the tuning table then falls back)."""
+    dtype = torch.float16
+    w, b = rnd(320, 320, dtype=torch.float32, s=0.05, seed=1), rnd(320, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    with pytest.raises(Exception):                                     # M not a multiple of the tile height
+        ops.linear(rnd(1000, 320, dtype=dtype), pw, tile=tile)
+    with pytest.raises(Exception):                                     # row vector
+        ops.linear(rnd(1024, 320, dtype=dtype), pw, rowvec=rnd(4, 320, dtype=dtype), rows_per_batch=256, tile=tile)
+    with pytest.raises(Exception):                                     # transposed store
+        ops.linear_t(rnd(1024, 320, dtype=dtype), pw, 512, torch.zeros(2, 320, 512, dtype=dtype, device=DEV), tile=tile)
+    with pytest.raises(Exception):                                     # f32 output
+        ops.linear(rnd(1024, 320, dtype=dtype), pw, out_f32=True, tile=tile)
+    with pytest.raises(Exception):                                     # split-K
+        ops.linear(rnd(1024, 320, dtype=dtype), pw, tile=tile + 200)
+    x = rnd(2, 16, 16, 64, dtype=dtype)
+    pc = ops.pack_conv3x3(rnd(64, 64, 3, 3, dtype=torch.float32, s=0.05, seed=1).cpu(), None, dtype, DEV)
+    with pytest.raises(Exception):                                     # convolution
+        ops.conv3x3(x, pc, tile=tile)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 ATT_CASES = [(2, 5, 1024, 1024), (1, 10, 256, 256), (2, 20, 64, 64), (2, 5, 1024, 77), (1, 2, 100, 77),
              (1, 1, 4096, 4096), (3, 4, 37, 200), (2, 20, 64, 77)]
