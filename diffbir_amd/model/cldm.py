@@ -78,7 +78,7 @@ class ControlLDM:
     def cast_dtype(self, dtype: torch.dtype) -> "ControlLDM":
         """reference cldm.py:174-210 casts UNet/ControlNet bodies; here it selects the MFMA compute dtype of the
         whole engine (VAE included: under the reference's autocast its convs run in the same 16-bit type)."""
-        for m in (self.unet, self.controlnet, self.vae):
+        for m in (self.unet, self.controlnet, self.vae, self.clip):
             m.set_dtype(dtype)
         self.unet.dtype = self.controlnet.dtype = dtype
         return self
@@ -118,13 +118,14 @@ class ControlLDM:
         c_txt, c_img = cond["c_txt"], cond["c_img"]
         self.unet._ensure_packed()
         self.controlnet._ensure_packed()
-        key = (tuple(x_noisy.shape), str(x_noisy.device), c_txt.data_ptr(), tuple(c_txt.shape), c_txt._version,
+        key = (tuple(x_noisy.shape), str(x_noisy.device), cond.get("cfg_pair"), c_txt.data_ptr(), tuple(c_txt.shape),
+               c_txt._version,
                tuple(float(s) for s in self.control_scales), str(self.unet._dtype), bool(self.overlap_streams),
                self.unet._gen, self.controlnet._gen)
         g = self._graphs.get(key)
         if g is None:
             try:
-                g = _EvalGraph(self, x_noisy, t, c_txt, c_img)
+                g = _EvalGraph(self, x_noisy, t, c_txt, c_img, cond.get("cfg_pair"))
             except Exception as e:  # capture not possible here: keep launching the same kernels eagerly
                 warnings.warn(f"diffbir_amd: HIP graph capture of the network evaluation failed ({e!r}); "
                               "continuing with eager launches")
@@ -141,22 +142,30 @@ class ControlLDM:
         self._graphs.clear()
 
     def _forward_eager(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
+        """cond may carry the engine extension `cfg_pair` = (G, bs): the samplers set it on the [uncond || cond] batch
+        they build for classifier-free guidance (identical x / t / c_img in both halves; model/unet.py docstring)."""
         c_txt, c_img = cond["c_txt"], cond["c_img"]
+        pair = cond.get("cfg_pair")
+        if pair is not None and os.environ.get("DBIR_CHECK_CFG_PAIR"):
+            G, bs = pair
+            for v in (x_noisy, t, c_img):
+                w = v.reshape(G, 2, bs, *v.shape[1:])
+                assert torch.equal(w[:, 0], w[:, 1]), "cfg_pair set on a batch whose halves differ"
         if not (self.overlap_streams and x_noisy.is_cuda):
-            control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales)
-            return self.unet(x_noisy, t, c_txt, control, only_mid_control=False)
+            control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales, pair=pair)
+            return self.unet(x_noisy, t, c_txt, control, only_mid_control=False, pair=pair)
         main = torch.cuda.current_stream()
         side = self._side_stream.get(x_noisy.device)
         if side is None:
             side = self._side_stream[x_noisy.device] = torch.cuda.Stream(device=x_noisy.device)
         side.wait_stream(main)                      # inputs produced on the main stream are ready
         with torch.cuda.stream(side):
-            control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales)
+            control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales, pair=pair)
             done = torch.cuda.Event()
             done.record(side)
         for c in control:                           # allocated on `side`, consumed (and later freed) on `main`
             c.record_stream(main)
-        return self.unet(x_noisy, t, c_txt, control, only_mid_control=False, control_ready=done)
+        return self.unet(x_noisy, t, c_txt, control, only_mid_control=False, control_ready=done, pair=pair)
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
@@ -166,13 +175,13 @@ class _EvalGraph:
     """One captured network evaluation.  All activations live in the graph's private memory pool (shared by every
     graph of one ControlLDM: they are replayed one at a time on one stream)."""
 
-    def __init__(self, cldm: ControlLDM, x: T, t: T, c_txt: T, c_img: T):
+    def __init__(self, cldm: ControlLDM, x: T, t: T, c_txt: T, c_img: T, pair=None):
         dev = x.device
         self.x = x.detach().float().contiguous().clone()
         self.t = t.detach().to(torch.float32).contiguous().clone()
         self.c_img = c_img.detach().float().contiguous().clone()
         self.c_txt = c_txt  # kept alive: the context K/V cache of the networks is keyed on its storage
-        cond = dict(c_txt=c_txt, c_img=self.c_img)
+        cond = dict(c_txt=c_txt, c_img=self.c_img, cfg_pair=pair)
         # warm-up outside the capture: packs weights, fills the context K/V cache, sizes split-K workspaces
         cldm._forward_eager(self.x, self.t, cond)
         torch.cuda.synchronize(dev)

@@ -1,8 +1,9 @@
-"""OpenCLIP text tower (FrozenOpenCLIPEmbedder, reference clip.py:8-61) — COLD path.
+"""OpenCLIP text tower (FrozenOpenCLIPEmbedder, reference clip.py:8-61).
 
-Two calls per pipeline run, 0.05 % of the FLOPs: kept on plain PyTorch-ROCm ops by design; only
-the text tower is built (the reference builds and deletes a ViT-H vision tower, clip.py:21-22).  State-dict keys
-are those below `cond_stage_model.` in SD checkpoints (`model.transformer.resblocks.N...`).
+Two calls per pipeline run, 0.05 % of the FLOPs.  Since round 2 the tower runs on the engine's
+own HIP kernels (csrc/clip.hip + the MFMA GEMM) instead of PyTorch-ROCm library ops; only the text tower is built
+(the reference builds and deletes a ViT-H vision tower, clip.py:21-22).  State-dict keys are those below
+`cond_stage_model.` in SD checkpoints (`model.transformer.resblocks.N...`).  The BPE tokenizer is host code.
 """
 import gzip
 import html
@@ -12,8 +13,8 @@ from functools import lru_cache
 from typing import Dict, List
 
 import torch
-import torch.nn.functional as F
 
+from .. import ops
 from .base import NativeModule
 from .specs import clip_text_spec
 
@@ -138,34 +139,53 @@ class FrozenOpenCLIPEmbedder(NativeModule):
         self.layer_idx = {"last": 0, "penultimate": 1}[layer]
 
     def _pack(self):
-        self.P = {k: v.to(self._device, torch.float32) for k, v in self._sd.items()}
+        """Weights of the blocks actually evaluated, packed for the MFMA GEMM in the engine dtype; embeddings and
+        LayerNorm affine parameters stay f32 (they feed the f32 residual stream)."""
+        t = self.cfg["text_cfg"]
+        f32 = lambda k: self._sd[k].to(self._device, torch.float32).contiguous()
+        lin = lambda w, b: ops.pack_linear(self._sd[w], self._sd[b], self._dtype, self._device)
+        self.tok_emb, self.pos = f32("model.token_embedding.weight"), f32("model.positional_embedding")
+        self.blocks = []
+        for i in range(t["layers"] - self.layer_idx):
+            p = f"model.transformer.resblocks.{i}"
+            self.blocks.append(dict(
+                ln1=(f32(p + ".ln_1.weight"), f32(p + ".ln_1.bias")), ln2=(f32(p + ".ln_2.weight"), f32(p + ".ln_2.bias")),
+                in_proj=lin(p + ".attn.in_proj_weight", p + ".attn.in_proj_bias"),
+                out_proj=lin(p + ".attn.out_proj.weight", p + ".attn.out_proj.bias"),
+                c_fc=lin(p + ".mlp.c_fc.weight", p + ".mlp.c_fc.bias"),
+                c_proj=lin(p + ".mlp.c_proj.weight", p + ".mlp.c_proj.bias")))
+        self.ln_final = (f32("model.ln_final.weight"), f32("model.ln_final.bias"))
 
-    def set_dtype(self, dtype):  # CLIP stays f32 (reference keeps fp32 weights; loop.py:82)
+    def set_dtype(self, dtype):
+        """The reference keeps CLIP's weights f32 (loop.py:82) and runs it under the pipeline's autocast
+        (loop.py:180): nn.Linear / attention in the 16-bit type, LayerNorm and the residual sums in f32.  Same split
+        here: GEMM operands in the engine dtype, f32 accumulation, f32 residual stream."""
+        if dtype != getattr(self, "_dtype", None):
+            self._dtype, self._packed = dtype, False
         return self
 
     def forward(self, tokens: T) -> T:
-        """reference clip.py:37-54: 23 of 24 pre-LN blocks with causal mask, then ln_final. -> f32 [B,77,W]."""
+        """reference clip.py:37-54: token + positional embedding, 23 of 24 pre-LN blocks with the causal mask, then
+        ln_final. tokens int64 [B, 77] -> f32 [B, 77, W].  Every step is a HIP kernel of this engine: dbir_clip_embed,
+        dbir_add_layernorm_f32 (residual add + LayerNorm fused), dbir_gemm (in_proj / out_proj / c_fc + GELU /
+        c_proj), dbir_causal_attention."""
         self._ensure_packed()
-        P, t = self.P, self.cfg["text_cfg"]
-        heads, L = t["heads"], t["layers"]
-        tokens = tokens.to(self._device)
-        x = P["model.token_embedding.weight"][tokens] + P["model.positional_embedding"]
-        n = x.shape[1]
-        mask = torch.full((n, n), float("-inf"), device=x.device).triu_(1)
-
-        def ln(p, v):
-            return F.layer_norm(v, (v.shape[-1],), P[p + ".weight"], P[p + ".bias"], 1e-5)
-
-        for i in range(L - self.layer_idx):
-            p = f"model.transformer.resblocks.{i}"
-            qkv = F.linear(ln(p + ".ln_1", x), P[p + ".attn.in_proj_weight"], P[p + ".attn.in_proj_bias"])
-            B, N, C3 = qkv.shape
-            q, k, v = qkv.reshape(B, N, 3, heads, C3 // 3 // heads).permute(2, 0, 3, 1, 4)
-            o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).permute(0, 2, 1, 3).reshape(B, N, C3 // 3)
-            x = x + F.linear(o, P[p + ".attn.out_proj.weight"], P[p + ".attn.out_proj.bias"])
-            hdn = F.gelu(F.linear(ln(p + ".ln_2", x), P[p + ".mlp.c_fc.weight"], P[p + ".mlp.c_fc.bias"]))
-            x = x + F.linear(hdn, P[p + ".mlp.c_proj.weight"], P[p + ".mlp.c_proj.bias"])
-        return ln("model.ln_final", x)
+        t = self.cfg["text_cfg"]
+        heads, W = t["heads"], t["width"]
+        assert W == heads * 64, "engine supports head_dim 64 text towers"
+        tokens = tokens.to(self._device, torch.int64).contiguous()
+        B, L = tokens.shape
+        x = ops.clip_embed(tokens, self.tok_emb, self.pos)          # f32 residual stream [B, L, W]
+        y = None
+        for blk in self.blocks:
+            n = ops.add_layernorm_f32(x, y, blk["ln1"][0], blk["ln1"][1], self._dtype)
+            qkv = ops.linear(n.reshape(B * L, W), blk["in_proj"]).reshape(B, L, 3 * W)
+            o = ops.causal_attention(qkv, heads, 64 ** -0.5)
+            y = ops.linear(o.reshape(B * L, W), blk["out_proj"], out_f32=True).reshape(B, L, W)
+            n = ops.add_layernorm_f32(x, y, blk["ln2"][0], blk["ln2"][1], self._dtype)
+            hdn = ops.linear(n.reshape(B * L, W), blk["c_fc"], act=ops.ACT_GELU)
+            y = ops.linear(hdn, blk["c_proj"], out_f32=True).reshape(B, L, W)
+        return ops.add_layernorm_f32(x, y, self.ln_final[0], self.ln_final[1], torch.float32)
 
     __call__ = forward
 

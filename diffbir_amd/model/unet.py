@@ -11,8 +11,15 @@ graph is re-expressed for the engine:
   * to_q/to_k are one GEMM, to_v is emitted transposed for the flash-attention kernel, cross-attention K/V of
     the (constant) text context are computed once per prompt and cached;
   * all per-ResBlock `emb_layers` (SiLU -> Linear, unet.py:166-172,212) are evaluated as ONE GEMM per network
-    evaluation, its column slices feed the conv epilogues.
+    evaluation, its column slices feed the conv epilogues;
+  * classifier-free guidance evaluates [uncond || cond] as one batch; the two halves have the SAME x, t and c_img
+    and differ only in the text context, so everything upstream of the first cross-attention (conv_in, the first
+    ResBlock, GroupNorm / proj_in / LayerNorm / q,k,v / self-attention / out-projection of the first transformer
+    block) is identical for both: with `pair=(G, bs)` it is evaluated once per distinct sample and duplicated right
+    before the first cross-attention (`_expand_pairs`).  Same arithmetic on the same operands — the reference
+    simply computes it twice (spaced_sampler.py:156-157).
 """
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -22,6 +29,22 @@ from .base import NativeModule
 from .specs import UNetPlan, controlnet_spec, unet_spec
 
 T = torch.Tensor
+Pair = Optional[Tuple[int, int]]
+# evaluate the part of the encoder that cannot depend on the text context once per distinct sample of a CFG batch
+SHARE_CFG_PREFIX = os.environ.get("DBIR_SHARE_CFG_PREFIX", "1") != "0"
+
+
+def _unique_of_pairs(t: T, pair: Tuple[int, int]) -> T:
+    """[G*2*bs, ...] laid out as G groups of (bs uncond, bs cond) with identical halves -> [G*bs, ...] (first halves)."""
+    G, bs = pair
+    return t.reshape(G, 2, bs, *t.shape[1:])[:, 0].reshape(G * bs, *t.shape[1:]).contiguous()
+
+
+def _expand_pairs(t: T, pair: Tuple[int, int]) -> T:
+    """Inverse of `_unique_of_pairs`: [G*bs, ...] -> [G*2*bs, ...] with both halves of every group equal (one copy)."""
+    G, bs = pair
+    rest = t.shape[1:]
+    return t.reshape(G, 1, bs, *rest).expand(G, 2, bs, *rest).reshape(G * 2 * bs, *rest)
 
 
 class _Res:
@@ -155,7 +178,8 @@ class _DiffusionNet(NativeModule):
         kv.append(c_txt)
         return kv
 
-    def _attn(self, a: _Attn, x: T, ctx_kv: list, out: Optional[T] = None) -> T:
+    def _attn(self, a: _Attn, x: T, ctx_kv: list, out: Optional[T] = None, pair: Pair = None) -> T:
+        """pair: x holds the distinct samples of a CFG batch; the result is the full batch (see module docstring)."""
         B, H, W, C = x.shape
         L = H * W
         scale = self.plan.head_dim ** -0.5
@@ -169,6 +193,11 @@ class _DiffusionNet(NativeModule):
         o = torch.empty((B, L, C), dtype=x.dtype, device=x.device)
         ops.attention(qk[..., :C], qk[..., C:], vt, o, a.heads, L, scale)
         h = ops.linear(o.reshape(B * L, C), a.out1, residual=h)
+        if pair is not None:  # first use of the text context: from here on the two halves differ
+            h = _expand_pairs(h.reshape(B, L, C), pair).reshape(2 * B * L, C)
+            x = _expand_pairs(x, pair)
+            B = 2 * B
+            o = torch.empty((B, L, C), dtype=x.dtype, device=x.device)
         # cross attention (K/V precomputed)
         n = ops.layernorm(h, a.ln2[0], a.ln2[1])
         q = ops.linear(n, a.q2).reshape(B, L, C)
@@ -190,9 +219,28 @@ class _DiffusionNet(NativeModule):
         h = self._res(res, h, emb_all)
         return self._attn(att, h, ctx_kv, out=out)
 
-    def _encode(self, h: T, emb_all: T, ctx_kv) -> Tuple[List[T], T]:
+    def _pair_ok(self, pair: Pair, batch: int) -> bool:
+        """The shared CFG prefix applies when the encoder starts conv_in -> (ResBlock + transformer)."""
+        if pair is None or not SHARE_CFG_PREFIX:
+            return False
+        G, bs = pair
+        assert G * 2 * bs == batch, (pair, batch)
+        return (len(self.enc) >= 2 and self.enc[0][0] == "conv_in" and self.enc[1][0] == "res"
+                and self.enc[1][2] is not None)
+
+    def _encode(self, h: T, emb_all: T, ctx_kv, pair: Pair = None) -> Tuple[List[T], T]:
+        """h: NHWC input; with `pair` it holds the DISTINCT samples only ([G*bs, ...]) while emb_all / ctx_kv are
+        those of the full [G*2*bs] batch."""
         hs = []
-        for blk in self.enc:
+        enc = self.enc
+        if pair is not None:
+            h = ops.conv3x3(h, enc[0][1])
+            hs.append(_expand_pairs(h, pair))
+            h = self._res(enc[1][1], h, _unique_of_pairs(emb_all, pair))
+            h = self._attn(enc[1][2], h, ctx_kv, pair=pair)
+            hs.append(h)
+            enc = enc[2:]
+        for blk in enc:
             if blk[0] == "conv_in":
                 h = ops.conv3x3(h, blk[1])
             elif blk[0] == "res":
@@ -226,15 +274,19 @@ class ControlledUnetModel(_DiffusionNet):
         self._finish_emb()
 
     def forward(self, x: T, timesteps: T, context: T, control: Optional[List[T]] = None,
-                only_mid_control: bool = False, control_ready=None, **_) -> T:
+                only_mid_control: bool = False, control_ready=None, pair: Pair = None, **_) -> T:
         """x: f32 NCHW [B,4,h,w]; control: list of 13 NHWC 16-bit tensors (already scaled) or None -> f32 NCHW.
         control_ready: optional torch.cuda.Event recorded by the stream that produces `control` (ControlLDM runs the
-        ControlNet concurrently with this encoder); waited for right before the first control tensor is read."""
+        ControlNet concurrently with this encoder); waited for right before the first control tensor is read.
+        pair=(G, bs): the caller guarantees the batch is G groups of [bs uncond || bs cond] whose halves have identical
+        x / timesteps (classifier-free guidance) — enables the shared prefix described in the module docstring."""
         self._ensure_packed()
         ctx_kv = self.context_kv(context)
         emb_all = self._time_emb(timesteps)
-        h = ops.nchw_to_nhwc(x.float().contiguous(), None, 8, self._dtype)
-        hs, h = self._encode(h, emb_all, ctx_kv)
+        x = x.float().contiguous()
+        pair = pair if self._pair_ok(pair, x.shape[0]) else None
+        h = ops.nchw_to_nhwc(x if pair is None else _unique_of_pairs(x, pair), None, 8, self._dtype)
+        hs, h = self._encode(h, emb_all, ctx_kv, pair)
         if control_ready is not None:
             torch.cuda.current_stream().wait_event(control_ready)
         control = list(control) if control is not None else None
@@ -290,13 +342,19 @@ class ControlNet(_DiffusionNet):
         self.zero.append(self._pk_lin("middle_block_out.0"))
         self._finish_emb()
 
-    def forward(self, x: T, hint: T, timesteps: T, context: T, scales: Optional[List[float]] = None, **_) -> List[T]:
-        """-> 13 control tensors (NHWC 16-bit), multiplied by `scales` (cldm.py:164) in the zero-conv epilogue."""
+    def forward(self, x: T, hint: T, timesteps: T, context: T, scales: Optional[List[float]] = None,
+                pair: Pair = None, **_) -> List[T]:
+        """-> 13 control tensors (NHWC 16-bit), multiplied by `scales` (cldm.py:164) in the zero-conv epilogue.
+        pair: as in ControlledUnetModel.forward (x, hint and timesteps identical in both halves of every group)."""
         self._ensure_packed()
         ctx_kv = self.context_kv(context)
         emb_all = self._time_emb(timesteps)
-        h = ops.nchw_to_nhwc(x.float().contiguous(), hint.float().contiguous(), 8, self._dtype)
-        hs, mid = self._encode(h, emb_all, ctx_kv)
+        x, hint = x.float().contiguous(), hint.float().contiguous()
+        pair = pair if self._pair_ok(pair, x.shape[0]) else None
+        if pair is not None:
+            x, hint = _unique_of_pairs(x, pair), _unique_of_pairs(hint, pair)
+        h = ops.nchw_to_nhwc(x, hint, 8, self._dtype)
+        hs, mid = self._encode(h, emb_all, ctx_kv, pair)
         feats = hs + [mid]
         scales = scales if scales is not None else [1.0] * len(feats)
         return [ops.linear(f, z, out_scale=float(s)) for f, z, s in zip(feats, self.zero, scales)]

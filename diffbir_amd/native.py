@@ -49,6 +49,9 @@ SIGNATURES = {
     "dbir_groupnorm_apply": [_I, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dbir_layernorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _F, _P],
     "dbir_softmax_rows": [_I, _P, _LL, _LL, _I, _P],
+    "dbir_clip_embed": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dbir_add_layernorm_f32": [_I, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _P],
+    "dbir_causal_attention": [_I, _P, _LL, _P, _LL, _I, _I, _I, _F, _P],
     "dbir_add_scaled": [_I, _P, _LL, _P, _LL, _F, _P, _LL, _LL, _I, _P],
     "dbir_nchw_to_nhwc": [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _F, _P],
     "dbir_nhwc_to_nchw": [_I, _P, _I, _LL, _P, _I, _I, _I, _I, _F, _P, _P],

@@ -415,6 +415,47 @@ def softmax_rows_(x: T, L: int) -> T:
     return x
 
 
+# ------------------------------------------------------------------------------------------------ CLIP text tower
+def clip_embed(tokens: T, tok_emb: T, pos: T) -> T:
+    """tokens int64 [B, L]; tok_emb f32 [vocab, W]; pos f32 [L, W] -> f32 [B, L, W] (token + positional embedding)."""
+    _gpu(tokens, tok_emb, pos)
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tok_emb.is_contiguous() and pos.is_contiguous()
+    assert tok_emb.dtype == torch.float32 and pos.dtype == torch.float32
+    B, L = tokens.shape
+    W = tok_emb.shape[1]
+    assert pos.shape[0] >= L and pos.shape[1] == W
+    x = torch.empty((B, L, W), dtype=torch.float32, device=tokens.device)
+    native.check(native.lib().dbir_clip_embed(tokens.data_ptr(), tok_emb.data_ptr(), pos.data_ptr(), x.data_ptr(), B, L,
+                                              W, tok_emb.shape[0], _stream()), "dbir_clip_embed")
+    return x
+
+
+def add_layernorm_f32(x: T, y: Optional[T], gamma: T, beta: T, out_dtype: torch.dtype, eps: float = 1e-5) -> T:
+    """x f32 [..., C] += y (f32 or None) IN PLACE; returns LayerNorm(x) * gamma + beta in `out_dtype` (16-bit: the next
+    GEMM's operand; f32: the tower's output)."""
+    _gpu(x, y, gamma, beta)
+    assert x.dtype == torch.float32 and x.is_contiguous() and (y is None or (y.dtype == torch.float32 and y.is_contiguous()
+                                                                              and y.shape == x.shape))
+    C = x.shape[-1]
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    f32 = out_dtype == torch.float32
+    native.check(native.lib().dbir_add_layernorm_f32(
+        native.F16 if f32 else (native.BF16 if out_dtype == torch.bfloat16 else native.F16), x.data_ptr(), None if y is None else y.data_ptr(), gamma.data_ptr(),
+        beta.data_ptr(), out.data_ptr(), C, int(f32), _rows(x), C, eps, _stream()), "dbir_add_layernorm_f32")
+    return out
+
+
+def causal_attention(qkv: T, heads: int, scale: float) -> T:
+    """qkv 16-bit [B, L, 3*heads*64] (q | k | v) -> [B, L, heads*64]; causal mask, L <= 128."""
+    _gpu(qkv)
+    assert qkv.stride(2) == 1 and qkv.stride(0) == qkv.shape[1] * qkv.stride(1)
+    B, L = qkv.shape[:2]
+    out = torch.empty((B, L, heads * 64), dtype=qkv.dtype, device=qkv.device)
+    native.check(native.lib().dbir_causal_attention(_dt(qkv), qkv.data_ptr(), qkv.stride(1), out.data_ptr(), heads * 64, B,
+                                                    heads, L, scale, _stream()), "dbir_causal_attention")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 def add_scaled(a: T, b: T, s: float, out: Optional[T] = None) -> T:
     _gpu(a, b, out)

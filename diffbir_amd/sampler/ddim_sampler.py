@@ -67,7 +67,7 @@ class DDIMSampler(Sampler):
         x = x_T.to(device=device, dtype=torch.float32).contiguous()
         use_cfg = not (uncond is None or cfg_scale == 1.0)
         if use_cfg:
-            cond2 = {k: torch.cat([uncond[k], cond[k]], dim=0).contiguous() for k in ("c_txt", "c_img")}
+            cond2 = self._cfg_batch(cond, uncond, bs)
         total = self.ddim_timesteps.shape[0]
         it = list(enumerate(np.flip(self.ddim_timesteps)))
         if progress:

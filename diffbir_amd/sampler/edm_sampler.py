@@ -108,7 +108,7 @@ class EDMSampler(Sampler):
     # ---------------------------------------------------------------- the denoiser
     def _denoiser(self, fwd, cond, uncond, cfg_scale: float, bs: int, device):
         use_cfg = not (uncond is None or cfg_scale == 1.0)
-        cond2 = ({k: torch.cat([uncond[k], cond[k]], dim=0).contiguous() for k in ("c_txt", "c_img")} if use_cfg else None)
+        cond2 = self._cfg_batch(cond, uncond, bs) if use_cfg else None
         full = lambda v: torch.full((bs,), float(v), device=device, dtype=torch.float32)
 
         def denoise(x: torch.Tensor, sigma) -> torch.Tensor:

@@ -25,6 +25,18 @@ class Sampler:
         from ..utils.tiling import TiledModel
         return TiledModel(forward, tile_size, tile_stride, shard=self.tile_shard, all_reduce=self.tile_all_reduce)
 
+    @staticmethod
+    def _cfg_batch(cond, uncond, bs: int) -> dict:
+        """The [uncond || cond] conditioning of the ONE batch-2B network evaluation that replaces the reference's two
+        batch-B forwards per step (spaced_sampler.py:156-157).  When both halves carry the same condition latent (they
+        always do when built by Pipeline.apply_cldm, pipeline.py:117-128) the batch is flagged `cfg_pair` = (groups,
+        bs): x, t and c_img of the two halves are identical, so the networks may share what precedes their first
+        cross-attention (model/unet.py).  Checked once per sample() call, not per step."""
+        cond2 = {k: torch.cat([uncond[k], cond[k]], dim=0).contiguous() for k in ("c_txt", "c_img")}
+        if uncond["c_img"].shape == cond["c_img"].shape and torch.equal(uncond["c_img"], cond["c_img"]):
+            cond2["cfg_pair"] = (1, bs)
+        return cond2
+
     def _randn(self, shape, device) -> torch.Tensor:
         if self.randn is not None:
             return self.randn(tuple(shape)).to(device=device, dtype=torch.float32).contiguous()

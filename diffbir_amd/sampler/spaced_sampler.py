@@ -85,7 +85,7 @@ class SpacedSampler(Sampler):
         k_x, k_o, c1, c2, sd = (per_b(v) for v in (k_x, k_o, tb["posterior_mean_coef1"], tb["posterior_mean_coef2"], sd))
         use_cfg = not (uncond is None or cfg_scale == 1.0)
         if use_cfg:
-            cond2 = {k: torch.cat([uncond[k], cond[k]], dim=0).contiguous() for k in ("c_txt", "c_img")}
+            cond2 = self._cfg_batch(cond, uncond, bs)
         total = len(self.timesteps)
         it = np.flip(self.timesteps)
         if progress:

@@ -92,8 +92,12 @@ class TiledModel:
         tiles = ops.tile_gather(x.float().contiguous(), coords, self.ts)
         t_rep = t.repeat(Tn)
         outs = []
+        pair = cond.get("cfg_pair")  # (1, bs): x = [bs uncond || bs cond] with equal halves -> per tile the same holds
         for i in range(0, n, step):
             j = min(n, i + step)
-            outs.append(self.forward(tiles[i:j], t_rep[i:j], {"c_txt": ctxt_rep[:j - i], "c_img": cimg_tiles[i:j]}))
+            c = {"c_txt": ctxt_rep[:j - i], "c_img": cimg_tiles[i:j]}
+            if pair is not None:
+                c["cfg_pair"] = ((j - i) // B, pair[1])   # chunks hold whole tiles: groups of [bs || bs]
+            outs.append(self.forward(tiles[i:j], t_rep[i:j], c))
         eps = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         return eps.contiguous()

@@ -165,6 +165,26 @@ int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, long long l
 int dbir_softmax_rows(int dtype, void* x, long long ld, long long rows, int L, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * OpenCLIP text tower (reference diffbir/model/clip.py:37-54 -> open_clip Transformer / ResidualAttentionBlock; its
+ * nn.Linear layers are dbir_gemm calls).  csrc/clip.hip.
+ * dbir_clip_embed: x[b, i, :] = token_embedding[tokens[b, i], :] + positional_embedding[i, :]  (f32 [B, L, W];
+ *   tokens int64 [B, L], ids clamped to [0, vocab)).  Replaces clip.py:43 (`token_embedding(tokens) + positional_embedding`).
+ * dbir_add_layernorm_f32: residual add + LayerNorm over f32 rows: x[rows, C] += y[rows, C] (y may be NULL) IN PLACE,
+ *   then out = LN(x) * gamma + beta as 16-bit (out_f32 = 0: the operand of the next GEMM, row stride ldo) or f32
+ *   (out_f32 = 1: ln_final).  Replaces `x = x + attn(ln_1(x))` / `x = x + mlp(ln_2(x))` / ln_final (clip.py:47-53) —
+ *   the residual stream stays f32 as under the reference's autocast.
+ * dbir_causal_attention: multi-head attention with the causal mask of the text tower (clip.py:46, attn_mask), head_dim
+ *   64, L <= 128: qkv 16-bit [B, L, ld] with q at columns [0, H*64), k at [H*64, 2*H*64), v at [2*H*64, 3*H*64) (the
+ *   in_proj layout of nn.MultiheadAttention); out 16-bit [B, L, ldo], columns [0, H*64).
+ */
+int dbir_clip_embed(const long long* tokens, const float* tok_emb, const float* pos, float* x, int B, int L, int W,
+                    int vocab, void* stream);
+int dbir_add_layernorm_f32(int dtype, float* x, const float* y, const float* gamma, const float* beta, void* out,
+                           long long ldo, int out_f32, int rows, int C, float eps, void* stream);
+int dbir_causal_attention(int dtype, const void* qkv, long long ld, void* out, long long ldo, int B, int H, int L,
+                          float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Layout / elementwise. */
 /* out[m, :C] (ldo) = a[m, :C] (lda) + s * b[m, :C] (ldb); 16-bit; C % 8 == 0.
  * (`hs.pop() + control.pop()` and `h += control.pop()` controlnet.py:37,43; writes straight into the

@@ -205,6 +205,24 @@ def layernorm(x, gamma, beta, C=None, eps=1e-5, out=None):
     return out
 
 
+def clip_embed(tokens, tok_emb, pos):
+    return tok_emb[tokens] + pos[: tokens.shape[1]]
+
+
+def add_layernorm_f32(x, y, gamma, beta, out_dtype, eps=1e-5):
+    if y is not None:
+        x.add_(y)
+    return F.layer_norm(x, (x.shape[-1],), gamma.float(), beta.float(), eps).to(out_dtype)
+
+
+def causal_attention(qkv, heads, scale):
+    B, L = qkv.shape[:2]
+    q, k, v = qkv[..., : 3 * heads * 64].float().reshape(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    mask = torch.full((L, L), float("-inf"), device=qkv.device).triu_(1)
+    p = torch.softmax(q @ k.transpose(-1, -2) * scale + mask, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B, L, heads * 64).to(qkv.dtype)
+
+
 def softmax_rows_(x, L):
     y = torch.zeros_like(x, dtype=torch.float32)
     y[..., :L] = torch.softmax(x[..., :L].float(), dim=-1)
@@ -318,7 +336,7 @@ def f32_nchw_to_u8_nhwc(src):
 
 
 _NAMES = ["linear", "linear_t", "conv3x3", "bmm_nt", "attention", "window_attention", "groupnorm", "groupnorm_stats",
-          "groupnorm_apply", "layernorm",
+          "groupnorm_apply", "layernorm", "clip_embed", "add_layernorm_f32", "causal_attention",
           "softmax_rows_", "add_scaled", "nchw_to_nhwc", "nhwc_to_nchw", "pixel_unshuffle", "timestep_embedding",
           "lincomb4", "spaced_step", "tile_gather", "tile_accumulate", "tile_accumulate_partial", "tile_normalize",
           "u8_to_f32_nchw", "wavelet_blur", "colorfix",

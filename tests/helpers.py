@@ -20,8 +20,8 @@ def build_engine(cfg_name: str, diffusion_cfg: str, device, dtype, W=None, raw_d
     cldm.clip.load_state_dict(W["clip"], strict=True)
     swin = SwinIR(**swin_cfg)
     swin.load_state_dict(W["swinir"], strict=True)
-    mods = [cldm.unet, cldm.controlnet, cldm.vae, swin]
-    for m in mods + [cldm.clip]:
+    mods = [cldm.unet, cldm.controlnet, cldm.vae, cldm.clip, swin]
+    for m in mods:
         m.to(device)
     for m in mods:
         if raw_dtype:

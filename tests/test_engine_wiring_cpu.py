@@ -184,3 +184,37 @@ def test_pipeline_error_behaviour_matches_reference(engine):
     from diffbir_amd.pipeline import SwinIRPipeline
     with pytest.raises(NotImplementedError):
         SwinIRPipeline(swin, cldm, pipe.diffusion, cond_fn=object(), device="cpu")
+
+
+@torch.no_grad()
+def test_cfg_pair_shared_prefix_is_exact(engine, monkeypatch):
+    """The CFG batch [uncond || cond] (identical x / t / c_img in both halves, different text) evaluated with the shared
+    encoder prefix (model/unet.py, `pair`) equals the plain batch-2B evaluation — for one group and for the tile-major
+    layout (G groups of [bs || bs]) the tiled scheduler produces — and really runs the prefix at half the batch."""
+    from diffbir_amd import ops
+    from diffbir_amd.model import unet as unet_mod
+    pipe, cldm, swin = engine
+    rs = cases.NoiseStream(3)
+    for G, bs in ((1, 2), (3, 1), (2, 2)):
+        xu, cu = rs((G, 1, bs, 4, 16, 16)), rs((G, 1, bs, 4, 16, 16)) * 0.5
+        x = xu.expand(G, 2, bs, 4, 16, 16).reshape(G * 2 * bs, 4, 16, 16).contiguous()
+        c_img = cu.expand(G, 2, bs, 4, 16, 16).reshape(G * 2 * bs, 4, 16, 16).contiguous()
+        t = torch.tensor([[float(100 + 37 * g + b) for b in range(bs)] * 2 for g in range(G)]).reshape(-1)
+        c_txt = rs((G * 2 * bs, 77, cldm.unet.cfg["context_dim"]))
+        plain = cldm(x, t, dict(c_txt=c_txt, c_img=c_img))
+        seen = []
+        real = ops.conv3x3
+        monkeypatch.setattr(ops, "conv3x3", lambda xx, *a, **k: (seen.append(xx.shape[0]), real(xx, *a, **k))[1])
+        monkeypatch.setenv("DBIR_CHECK_CFG_PAIR", "1")
+        shared = cldm(x, t, dict(c_txt=c_txt, c_img=c_img, cfg_pair=(G, bs)))
+        monkeypatch.setattr(ops, "conv3x3", real)
+        assert rel_err(shared, plain.numpy())[0] < 1e-5
+        # per network: conv_in + the two ResBlock convs of input_blocks.1 at the distinct-sample batch
+        assert seen.count(G * bs) == 6 and set(seen) == {G * bs, G * 2 * bs}, seen
+    # halves that differ must be caught by the debug check
+    bad = x.clone()
+    bad[0] += 1.0
+    with pytest.raises(AssertionError):
+        cldm(bad, t, dict(c_txt=c_txt, c_img=c_img, cfg_pair=(G, bs)))
+    monkeypatch.setattr(unet_mod, "SHARE_CFG_PREFIX", False)
+    assert rel_err(cldm(x, t, dict(c_txt=c_txt, c_img=c_img, cfg_pair=(G, bs))), plain.numpy())[0] == 0.0

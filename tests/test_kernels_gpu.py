@@ -687,6 +687,40 @@ def test_softmax_rows(dtype):
     check("softmax_rows", ops.softmax_rows_(a, 1030), emu.softmax_rows_(b, 1030), dtype)
 
 
+# ------------------------------------------------------------------------------------------------ CLIP text tower
+def test_clip_embed():
+    g = torch.Generator().manual_seed(5)
+    tok = torch.randint(0, 1000, (3, 77), generator=g).to(DEV)
+    emb, pos = rnd(1000, 1024, dtype=torch.float32), rnd(77, 1024, dtype=torch.float32, seed=1)
+    got = ops.clip_embed(tok, emb, pos)
+    assert got.dtype == torch.float32 and torch.equal(got, emu.clip_embed(tok, emb, pos))   # one f32 add: exact
+
+
+@pytest.mark.parametrize("dtype", DTYPES + [torch.float32])
+@pytest.mark.parametrize("rows,C", [(154, 1024), (5, 64), (231, 1280)])
+def test_add_layernorm_f32(rows, C, dtype):
+    x = rnd(rows, C, dtype=torch.float32, s=3.0) + 0.7
+    y = rnd(rows, C, dtype=torch.float32, seed=3)
+    g, b = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=1), 0.1 * rnd(C, dtype=torch.float32, seed=2)
+    for yy in (y, None):
+        xa, xb = x.clone(), x.clone()
+        got, ref = ops.add_layernorm_f32(xa, yy, g, b, dtype), emu.add_layernorm_f32(xb, yy, g, b, dtype)
+        assert got.dtype == dtype and torch.equal(xa, xb)      # the residual stream update is one f32 add: exact
+        check(f"add_layernorm_f32 {rows}x{C} y={yy is not None}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,L", [(2, 16, 77), (1, 3, 128), (3, 2, 1), (1, 1, 8)])
+def test_causal_attention(B, H, L, dtype):
+    qkv = rnd(B, L, 3 * H * 64, dtype=dtype, s=1.5)
+    check(f"causal_attention B{B} H{H} L{L}", ops.causal_attention(qkv, H, 0.125), emu.causal_attention(qkv, H, 0.125), dtype)
+    # causality: the output at position i must not depend on later tokens
+    q2 = qkv.clone()
+    q2[:, L // 2 + 1:] = rnd(B, L - L // 2 - 1, 3 * H * 64, dtype=dtype, seed=9)
+    a, b = ops.causal_attention(qkv, H, 0.125), ops.causal_attention(q2, H, 0.125)
+    assert torch.equal(a[:, : L // 2 + 1], b[:, : L // 2 + 1])
+
+
 # ------------------------------------------------------------------------------------------------ elementwise & co
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_and_elementwise(dtype):

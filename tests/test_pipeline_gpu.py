@@ -65,7 +65,8 @@ def test_modules_vs_reference_golden(golden_dir, cfg, img, dtype):
     REPORT[f"modules_{cfg}_{dtype}"] = {k: v[0] for k, v in res.items()}
     print(cfg, dtype, {k: f"{v[0]:.2e}" for k, v in res.items()})
     tol = MOD_TOL[dtype]
-    bad = {k: v[0] for k, v in res.items() if not (v[0] < (1e-4 if k == "c_txt" else tol))}
+    # c_txt: the text tower runs on the engine's 16-bit MFMA GEMMs (f32 residual stream): same bar as the other modules
+    bad = {k: v[0] for k, v in res.items() if not (v[0] < tol)}
     assert not bad, bad
 
 
