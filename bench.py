@@ -149,11 +149,14 @@ def measure_roofline(cldm, device, batch):
     on) of every implicit-GEMM launch of ONE batched network evaluation (ControlNet + UNet at batch 2B)."""
     import torch
     from diffbir_amd import ops
-    x = torch.randn(2 * batch, 4, 64, 64, device=device)
-    c_img = torch.randn(2 * batch, 4, 64, 64, device=device)
+    # the evaluation the samplers issue under CFG: [uncond || cond] with identical x / t / c_img in both halves
+    # (`cfg_pair`: the encoder prefix upstream of the first cross-attention runs once per distinct sample, model/unet.py)
+    # — FLOPs below are those of the launches actually executed, not the reference's 2 x batch-B count
+    x = torch.randn(batch, 4, 64, 64, device=device).repeat(2, 1, 1, 1)
+    c_img = torch.randn(batch, 4, 64, 64, device=device).repeat(2, 1, 1, 1)
     c_txt = torch.randn(2 * batch, 77, 1024, device=device)
     t = torch.full((2 * batch,), 500.0, device=device)
-    cond = dict(c_txt=c_txt, c_img=c_img)
+    cond = dict(c_txt=c_txt, c_img=c_img, cfg_pair=(1, batch))
     overlap, cldm.overlap_streams = cldm.overlap_streams, False   # per-launch durations are measured un-overlapped
     graph, cldm.use_graph = cldm.use_graph, False
     cldm(x, t, cond)  # warm (context K/V cache, allocator)

@@ -270,6 +270,65 @@ def swinir_spec(cfg: dict) -> Spec:
 
 
 # --------------------------------------------------------------------------------------------
+# BSRNet (RRDBNet, reference bsrnet.py:75-104) and SCUNet (scunet.py:163-264) stage-1 cleaners
+# --------------------------------------------------------------------------------------------
+def bsrnet_spec(cfg: dict) -> Spec:
+    nf, gc, nb, sf = cfg.get("nf", 64), cfg.get("gc", 32), cfg.get("nb", 23), cfg.get("sf", 4)
+    assert sf in (2, 4), "RRDBNet: sf 2 or 4 (bsrnet.py:87-88, 99-100)"
+    sp = OrderedDict()
+    _conv(sp, "conv_first", cfg.get("in_nc", 3), nf, 3)
+    for i in range(nb):
+        for r in (1, 2, 3):
+            p = f"RRDB_trunk.{i}.RDB{r}"
+            for k in range(4):
+                _conv(sp, f"{p}.conv{k + 1}", nf + k * gc, gc, 3)
+            _conv(sp, f"{p}.conv5", nf + 4 * gc, nf, 3)
+    _conv(sp, "trunk_conv", nf, nf, 3)
+    _conv(sp, "upconv1", nf, nf, 3)
+    if sf == 4:
+        _conv(sp, "upconv2", nf, nf, 3)
+    _conv(sp, "HRconv", nf, nf, 3)
+    _conv(sp, "conv_last", nf, cfg.get("out_nc", 3), 3)
+    return sp
+
+
+def scunet_stages(cfg: dict):
+    """(state-dict prefix, block channels (conv_dim == trans_dim == ch // 2 ... see below), #blocks, first index) per
+    stage, in forward order.  ConvTransBlock(conv_dim=c, trans_dim=c) works on 2c channels (scunet.py:173-206)."""
+    dim, n = cfg.get("dim", 64), list(cfg.get("config", [2] * 7))
+    return [("m_down1", dim // 2, n[0], 0), ("m_down2", dim, n[1], 0), ("m_down3", 2 * dim, n[2], 0),
+            ("m_body", 4 * dim, n[3], 0), ("m_up3", 2 * dim, n[4], 1), ("m_up2", dim, n[5], 1),
+            ("m_up1", dim // 2, n[6], 1)]
+
+
+def scunet_spec(cfg: dict) -> Spec:
+    dim, in_nc, hd, ws = cfg.get("dim", 64), cfg.get("in_nc", 3), 32, 8
+    sp = OrderedDict()
+    sp["m_head.0.weight"] = ((dim, in_nc, 3, 3), "w")
+    for name, c, nblk, first in scunet_stages(cfg):
+        if first == 1:  # ConvTranspose2d(4c, 2c, 2, 2): weight [in, out, 2, 2]
+            sp[f"{name}.0.weight"] = ((4 * c, 2 * c, 2, 2), "w")
+        for i in range(nblk):
+            p = f"{name}.{i + first}"
+            t = f"{p}.trans_block"
+            _norm(sp, f"{t}.ln1", c)
+            sp[f"{t}.msa.relative_position_params"] = ((c // hd, 2 * ws - 1, 2 * ws - 1), "e")
+            _lin(sp, f"{t}.msa.embedding_layer", c, 3 * c)
+            _lin(sp, f"{t}.msa.linear", c, c)
+            _norm(sp, f"{t}.ln2", c)
+            _lin(sp, f"{t}.mlp.0", c, 4 * c)
+            _lin(sp, f"{t}.mlp.2", 4 * c, c)
+            _conv(sp, f"{p}.conv1_1", 2 * c, 2 * c, 1)
+            _conv(sp, f"{p}.conv1_2", 2 * c, 2 * c, 1)
+            sp[f"{p}.conv_block.0.weight"] = ((c, c, 3, 3), "w")
+            sp[f"{p}.conv_block.2.weight"] = ((c, c, 3, 3), "w")
+        if name.startswith("m_down"):  # Conv2d(2c, 4c, 2, 2)
+            sp[f"{name}.{nblk}.weight"] = ((4 * c, 2 * c, 2, 2), "w")
+    sp["m_tail.0.weight"] = ((in_nc, dim, 3, 3), "w")
+    return sp
+
+
+# --------------------------------------------------------------------------------------------
 # OpenCLIP text tower (keys below FrozenOpenCLIPEmbedder, i.e. prefixed "model.")
 # --------------------------------------------------------------------------------------------
 def clip_text_spec(cfg: dict) -> Spec:

@@ -44,7 +44,8 @@ def _expand_pairs(t: T, pair: Tuple[int, int]) -> T:
     """Inverse of `_unique_of_pairs`: [G*bs, ...] -> [G*2*bs, ...] with both halves of every group equal (one copy)."""
     G, bs = pair
     rest = t.shape[1:]
-    return t.reshape(G, 1, bs, *rest).expand(G, 2, bs, *rest).reshape(G * 2 * bs, *rest)
+    # .contiguous(): materialise — for G == bs == 1 the reshape of the expanded view would stay a stride-0 view
+    return t.reshape(G, 1, bs, *rest).expand(G, 2, bs, *rest).contiguous().reshape(G * 2 * bs, *rest)
 
 
 class _Res:
