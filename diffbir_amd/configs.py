@@ -1,6 +1,6 @@
 """Built-in network configurations.
 
-`FULL_*` reproduce the values of the reference's configs/inference/{cldm,swinir,diffusion,diffusion_v2.1}.yaml
+`FULL_*` reproduce the values of the reference's configs/inference/{cldm,swinir,bsrnet,scunet,diffusion,diffusion_v2.1}.yaml
 (the config surface); `TINY_*` are structurally identical, narrow networks used by the
 parity tests and golden fixtures (they run through the reference on CPU in seconds).
 """
@@ -39,6 +39,11 @@ FULL_SWINIR = dict(img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths=
                    window_size=8, mlp_ratio=2, sf=8, img_range=1.0, upsampler="nearest+conv",
                    resi_connection="1conv", unshuffle=True, unshuffle_scale=8)
 
+FULL_BSRNET = dict(in_nc=3, out_nc=3, nf=64, nb=23, gc=32, sf=4)          # configs/inference/bsrnet.yaml
+FULL_SCUNET = dict(in_nc=3, config=[4, 4, 4, 4, 4, 4, 4], dim=64)        # configs/inference/scunet.yaml
+TINY_BSRNET = dict(in_nc=3, out_nc=3, nf=16, nb=2, gc=8, sf=4)
+TINY_SCUNET = dict(in_nc=3, config=[2, 1, 2, 1, 2, 1, 2], dim=64)        # dim/2 must stay a multiple of head_dim 32
+
 DIFFUSION_V2 = dict(linear_start=0.00085, linear_end=0.0120, timesteps=1000)
 DIFFUSION_V21 = dict(linear_start=0.00085, linear_end=0.0120, timesteps=1000, zero_snr=True,
                      parameterization="v")
@@ -58,6 +63,8 @@ def get(name: str) -> dict:
 _YAML = {
     "cldm": ("diffbir.model.ControlLDM", "FULL_CLDM"),
     "swinir": ("diffbir.model.SwinIR", "FULL_SWINIR"),
+    "bsrnet": ("diffbir.model.RRDBNet", "FULL_BSRNET"),
+    "scunet": ("diffbir.model.SCUNet", "FULL_SCUNET"),
     "diffusion": ("diffbir.model.Diffusion", "DIFFUSION_V2"),
     "diffusion_v2.1": ("diffbir.model.Diffusion", "DIFFUSION_V21"),
 }

@@ -27,6 +27,32 @@ __global__ void add_scaled_kernel(const u16* __restrict__ a, long long lda, cons
   }
 }
 
+// 2x2 pixel-block <-> channel regrouping of NHWC 16-bit tensors (dtype-agnostic 16-byte moves):
+//   to_depth = 1: dst[b, i, j, (ky*2 + kx)*C + c] = src[b, 2i+ky, 2j+kx, c]     ([B,2h,2w,C] -> [B,h,w,4C])
+//   to_depth = 0: dst[b, 2i+ky, 2j+kx, c] = src[b, i, j, (ky*2 + kx)*C + c]     ([B,h,w,4C] -> [B,2h,2w,C])
+// so that Conv2d(k=2, s=2) and ConvTranspose2d(k=2, s=2) (SCUNet down / up sampling, scunet.py:179-212) become plain
+// GEMMs with K = 4C resp. N = 4C.  h, w: the LOW-resolution extent; lds / ldd row strides in elements.
+__global__ void block2x2_kernel(const u16* __restrict__ src, long long lds, u16* __restrict__ dst, long long ldd,
+                                int B, int h, int w, int CV, int to_depth) {
+  GRID_STRIDE(i, (long long)B * h * w * 4 * CV) {
+    const int cv = (int)(i % CV);
+    long long r = i / CV;
+    const int q = (int)(r & 3);
+    r >>= 2;
+    const int jj = (int)(r % w);
+    r /= w;
+    const int ii = (int)(r % h);
+    const long long b = r / h;
+    const long long hi = (b * 2 * h + 2 * ii + (q >> 1)) * (2LL * w) + 2 * jj + (q & 1);  // high-resolution pixel
+    const long long lo = (b * h + ii) * (long long)w + jj;                                  // low-resolution pixel
+    const long long ch = (long long)q * CV * 8 + cv * 8;
+    if (to_depth)
+      *reinterpret_cast<uint4*>(dst + lo * ldd + ch) = *reinterpret_cast<const uint4*>(src + hi * lds + cv * 8);
+    else
+      *reinterpret_cast<uint4*>(dst + hi * ldd + cv * 8) = *reinterpret_cast<const uint4*>(src + lo * lds + ch);
+  }
+}
+
 // NCHW f32 (one or two sources concatenated along C) -> NHWC 16-bit, zero padded to Cpad (Cpad <= 16 typical)
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ s0, int C0, const float* __restrict__ s1, int C1,
@@ -270,6 +296,19 @@ extern "C" int dbir_add_scaled(int dtype, const void* a, long long lda, const vo
   BY_DTYPE(add_scaled_kernel, grid_for(M * (C / 8)), (const u16*)a, lda, (const u16*)b, ldb, s, (u16*)out, ldo, M,
            C / 8);
   DBIR_CHECK_LAUNCH("dbir_add_scaled");
+  return DBIR_OK;
+}
+
+extern "C" int dbir_block2x2(const void* src, long long lds, void* dst, long long ldd, int B, int h, int w, int C,
+                             int to_depth, void* stream) {
+  DBIR_CHECK_ARG(src && dst && B > 0 && h > 0 && w > 0 && C > 0 && C % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0,
+                 "dbir_block2x2: bad args (C and the row strides must be multiples of 8)");
+  DBIR_CHECK_ARG(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
+                 "dbir_block2x2: 16-byte aligned tensors");
+  DBIR_CHECK_ARG(to_depth ? (lds >= C && ldd >= 4LL * C) : (lds >= 4LL * C && ldd >= C), "dbir_block2x2: bad row strides");
+  hipLaunchKernelGGL(block2x2_kernel, grid_for((long long)B * h * w * 4 * (C / 8)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (const u16*)src, lds, (u16*)dst, ldd, B, h, w, C / 8, to_depth);
+  DBIR_CHECK_LAUNCH("dbir_block2x2");
   return DBIR_OK;
 }
 

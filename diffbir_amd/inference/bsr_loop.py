@@ -1,25 +1,33 @@
-"""Blind super-resolution loop (reference diffbir/inference/bsr_loop.py:18-59)."""
+"""Blind super-resolution loop (reference diffbir/inference/bsr_loop.py:18-59): SwinIR cleaner for v1 / v2.1, the BSRNet
+(RRDBNet x4) cleaner + BSRNetPipeline for v2."""
 import numpy as np
 
-from ..pipeline import SwinIRPipeline
+from ..pipeline import BSRNetPipeline, SwinIRPipeline
 from ..utils.common import instantiate_from_config, load_model_from_url
 from .loop import MODELS, InferenceLoop, load_config
 
 
 class BSRInferenceLoop(InferenceLoop):
     def load_cleaner(self) -> None:
-        if self.args.version == "v2":
-            raise NotImplementedError("DiffBIR v2 BSR uses the BSRNet (RRDBNet) cleaner, which is outside this engine's "
-                                      "hot-path scope (SURVEY.md §8f N3); use --version v1 or v2.1 (SwinIR)")
-        weight = MODELS["swinir_general" if self.args.version == "v1" else "swinir_realesrgan"]
-        self.cleaner = instantiate_from_config(load_config("swinir"))
+        if self.args.version == "v1":
+            config, weight = "swinir", MODELS["swinir_general"]
+        elif self.args.version == "v2":
+            config, weight = "bsrnet", MODELS["bsrnet"]
+        else:
+            config, weight = "swinir", MODELS["swinir_realesrgan"]
+        self.cleaner = instantiate_from_config(load_config(config))
         self.cleaner.load_state_dict(load_model_from_url(weight), strict=True)
         self.cleaner.eval().to(self.args.device)
 
     def load_pipeline(self) -> None:
-        self.pipeline = SwinIRPipeline(self.cleaner, self.cldm, self.diffusion, self.cond_fn, self.args.device)
+        if self.args.version in ("v1", "v2.1"):
+            self.pipeline = SwinIRPipeline(self.cleaner, self.cldm, self.diffusion, self.cond_fn, self.args.device)
+        else:
+            self.pipeline = BSRNetPipeline(self.cleaner, self.cldm, self.diffusion, self.cond_fn, self.args.device,
+                                           self.args.upscale)
 
     def after_load_lq(self, lq) -> np.ndarray:
-        from PIL import Image
-        lq = lq.resize(tuple(int(x * self.args.upscale) for x in lq.size), Image.BICUBIC)
+        if self.args.version in ("v1", "v2.1"):   # BSRNet up-scales by itself (bsr_loop.py:54-58)
+            from PIL import Image
+            lq = lq.resize(tuple(int(x * self.args.upscale) for x in lq.size), Image.BICUBIC)
         return super().after_load_lq(lq)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "dbir_add_layernorm_f32": [_I, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _P],
     "dbir_causal_attention": [_I, _P, _LL, _P, _LL, _I, _I, _I, _F, _P],
     "dbir_add_scaled": [_I, _P, _LL, _P, _LL, _F, _P, _LL, _LL, _I, _P],
+    "dbir_block2x2": [_P, _LL, _P, _LL, _I, _I, _I, _I, _I, _P],
     "dbir_nchw_to_nhwc": [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _F, _P],
     "dbir_nhwc_to_nchw": [_I, _P, _I, _LL, _P, _I, _I, _I, _I, _F, _P, _P],
     "dbir_pixel_unshuffle": [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],

@@ -466,6 +466,29 @@ def add_scaled(a: T, b: T, s: float, out: Optional[T] = None) -> T:
     return out
 
 
+def space_to_depth2(x: T) -> T:
+    """[B, 2h, 2w, C] 16-bit NHWC (row stride may exceed C) -> [B, h, w, 4C], channel = (ky*2 + kx)*C + c."""
+    _gpu(x)
+    B, H, W, C = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    out = torch.empty((B, H // 2, W // 2, 4 * C), dtype=x.dtype, device=x.device)
+    native.check(native.lib().dbir_block2x2(x.data_ptr(), _ld(x), out.data_ptr(), 4 * C, B, H // 2, W // 2, C, 1,
+                                            _stream()), "dbir_block2x2")
+    return out
+
+
+def depth_to_space2(x: T, out: Optional[T] = None) -> T:
+    """[B, h, w, 4C] -> [B, 2h, 2w, C] (inverse of space_to_depth2); `out` may be a column slice of a wider buffer."""
+    _gpu(x, out)
+    B, h, w, C4 = x.shape
+    C = C4 // 4
+    if out is None:
+        out = torch.empty((B, 2 * h, 2 * w, C), dtype=x.dtype, device=x.device)
+    native.check(native.lib().dbir_block2x2(x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), B, h, w, C, 0, _stream()),
+                 "dbir_block2x2")
+    return out
+
+
 def nchw_to_nhwc(src0: T, src1: Optional[T], cpad: int, dtype, scale: float = 1.0, shift: float = 0.0) -> T:
     _gpu(src0, src1)
     assert src0.dtype == torch.float32 and src0.is_contiguous() and (src1 is None or src1.is_contiguous())

@@ -187,3 +187,40 @@ class SwinIRPipeline(Pipeline):
         if min(output.shape[2:]) < 512:
             output = resize_short_edge_to(output, size=512)
         return output
+
+
+class BSRNetPipeline(Pipeline):
+    """reference pipeline.py:324-366: the x4 RRDBNet cleaner runs on the LQ image itself; its output is resized to the
+    requested upscale (bicubic + antialias: cold path on PyTorch, like the reference)."""
+
+    def __init__(self, cleaner, cldm, diffusion, cond_fn, device: str, upscale: float) -> None:
+        super().__init__(cleaner, cldm, diffusion, cond_fn, device)
+        self.upscale = upscale
+
+    def set_output_size(self, lq_size: Tuple[int]) -> None:
+        h, w = lq_size[2:]
+        self.output_size = (int(h * self.upscale), int(w * self.upscale))
+
+    def apply_cleaner(self, lq: torch.Tensor, tiled: bool, tile_size: int, tile_stride: int) -> torch.Tensor:
+        if tiled and (lq.size(2) < tile_size or lq.size(3) < tile_size):
+            print("[BSRNet]: the input size is tiny and unnecessary to tile.")
+            tiled = False
+        model = make_tiled_fn(self.cleaner, tile_size, tile_stride, scale_type="up", scale=4) if tiled else self.cleaner
+        output_upscale4 = model(lq)
+        if min(self.output_size) < 512:
+            return resize_short_edge_to(output_upscale4, size=512)
+        return F.interpolate(output_upscale4, size=self.output_size, mode="bicubic", antialias=True)
+
+
+class SCUNetPipeline(Pipeline):
+    """reference pipeline.py:400-420 (blind image denoising, DiffBIR v2)."""
+
+    def apply_cleaner(self, lq: torch.Tensor, tiled: bool, tile_size: int, tile_stride: int) -> torch.Tensor:
+        if tiled and (lq.size(2) < tile_size or lq.size(3) < tile_size):
+            print("[SCUNet]: the input size is tiny and unnecessary to tile.")
+            tiled = False
+        model = make_tiled_fn(self.cleaner, tile_size, tile_stride) if tiled else self.cleaner
+        output = model(lq)
+        if min(output.shape[2:]) < 512:
+            output = resize_short_edge_to(output, size=512)
+        return output

@@ -87,14 +87,17 @@ def make_tiled_fn(fn: Callable, size: int, stride: int, scale_type: str = "up", 
     All tiles are gathered by one kernel, `fn` runs per tile (its batch is the image batch, as in the reference) and
     one kernel does the weighted accumulate + normalise in the reference's tile order.  The diffusion model uses
     the batched scheduler in utils/tiling.py instead."""
-    if scale != 1 or scale_type != "up":
-        raise NotImplementedError("only scale=1 tiling is on the SwinIR / ControlLDM path")
+    if scale_type != "up" or int(scale) != scale or scale < 1:
+        raise NotImplementedError("tiling with an integer up-scale (1: SwinIR / SCUNet / ControlLDM, 4: BSRNet) is on "
+                                  "the hot path; the reference never uses scale_type='down'")
+    scale = int(scale)
 
     def tiled_fn(x: T, *args, **kwargs) -> T:
         b, c, h, w = x.shape
         wins = sliding_windows(h, w, size, stride)
         coords = torch.tensor([[hi, wi] for hi, _, wi, _ in wins], dtype=torch.int32, device=x.device)
-        wt = gaussian_weights(size, size) if weight == "gaussian" else np.ones((size, size))
+        so = size * scale   # output tiles, weights and paste positions are those of the up-scaled grid (common.py:183-222)
+        wt = gaussian_weights(so, so) if weight == "gaussian" else np.ones((so, so))
         wt = torch.tensor(wt, dtype=torch.float32, device=x.device)
         tiles = ops.tile_gather(x.float().contiguous(), coords, size)
         outs = []
@@ -103,7 +106,7 @@ def make_tiled_fn(fn: Callable, size: int, stride: int, scale_type: str = "up", 
             if len(args) or len(kwargs):
                 kw.update(dict(hi=hi, hi_end=he, wi=wi, wi_end=we))
             outs.append(fn(tiles[t * b:(t + 1) * b], *args, **kw).float())
-        return ops.tile_accumulate(torch.cat(outs, dim=0).contiguous(), wt, coords, b, h, w)
+        return ops.tile_accumulate(torch.cat(outs, dim=0).contiguous(), wt, coords * scale, b, h * scale, w * scale)
 
     return tiled_fn
 

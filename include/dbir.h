@@ -191,6 +191,13 @@ int dbir_causal_attention(int dtype, const void* qkv, long long ld, void* out, l
  * concat buffer that replaces torch.cat controlnet.py:41-43.) */
 int dbir_add_scaled(int dtype, const void* a, long long lda, const void* b, long long ldb, float s, void* out,
                     long long ldo, long long M, int C, void* stream);
+/* 2x2 pixel-block <-> channel regrouping of NHWC 16-bit tensors (any 16-bit dtype; 16-byte moves):
+ *   to_depth = 1: dst[b,i,j,(ky*2+kx)*C + c] = src[b,2i+ky,2j+kx,c]   ([B,2h,2w,C] -> [B,h,w,4C])
+ *   to_depth = 0: dst[b,2i+ky,2j+kx,c] = src[b,i,j,(ky*2+kx)*C + c]   ([B,h,w,4C] -> [B,2h,2w,C])
+ * h, w = the low-resolution extent.  Turns nn.Conv2d(k=2, s=2) / nn.ConvTranspose2d(k=2, s=2) of SCUNet
+ * (scunet.py:179-212) into plain dbir_gemm calls. */
+int dbir_block2x2(const void* src, long long lds, void* dst, long long ldd, int B, int h, int w, int C, int to_depth,
+                  void* stream);
 /* NCHW f32 sources -> NHWC 16-bit [B,H,W,Cpad]: channels = cat(src0[C0], src1[C1]) * scale + shift, zero
  * padded to Cpad.  (torch.cat((x, hint)) controlnet.py:317; `.type(self.dtype)` :320; `img*2-1` cldm.py:153.) */
 int dbir_nchw_to_nhwc(int dtype, const float* src0, int C0, const float* src1, int C1, void* dst, int Cpad, int B,

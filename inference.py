@@ -105,13 +105,13 @@ def main(argv=None):
     args = parse_args(argv)
     args.device = check_device(args.device)
     set_seed(args.seed)
-    from diffbir.inference import BFRInferenceLoop, BSRInferenceLoop
+    from diffbir.inference import BFRInferenceLoop, BIDInferenceLoop, BSRInferenceLoop
     if args.version == "custom":
         raise SystemExit("--version custom (self-trained models through the training config) is outside this engine")
-    loops = {"sr": BSRInferenceLoop, "face": BFRInferenceLoop}
+    loops = {"sr": BSRInferenceLoop, "face": BFRInferenceLoop, "denoise": BIDInferenceLoop}
     if args.task not in loops:
-        raise SystemExit(f"--task {args.task}: its stage-1 model (SCUNet / RetinaFace front-end) is outside this engine's "
-                         "scope; supported: sr, face")
+        raise SystemExit(f"--task {args.task}: the RetinaFace detection / alignment front-end is outside this engine's "
+                         "scope; supported: sr, face, denoise")
     loops[args.task](args).run()
     print("done!")
 

@@ -44,6 +44,36 @@ def synth_weights(cldm_cfg: dict, swinir_cfg: dict, seed: int = 0) -> Dict[str, 
     return W
 
 
+# BSRNet / SCUNet cleaners: seeded weights with a gain that keeps activations O(1) through the 23 RRDBs /
+# 28 ConvTransBlocks (unit gain grows to 1e5 at the SCUNet output — meaningless in 16 bit), and the module-level inputs
+CLEANERS = {
+    "bsrnet_tiny": ("TINY_BSRNET", 0.7, (2, 3, 40, 56)), "bsrnet_full": ("FULL_BSRNET", 0.7, (2, 3, 40, 56)),
+    "scunet_tiny": ("TINY_SCUNET", 0.6, (2, 3, 100, 136)), "scunet_full": ("FULL_SCUNET", 0.6, (2, 3, 100, 136)),
+}
+
+
+def cleaner_case(name: str):
+    """-> (cfg, weights, input f32 NCHW in [0, 1])."""
+    key, gain, shape = CLEANERS[name]
+    cfg = configs.get(key)
+    spec = specs.bsrnet_spec(cfg) if name.startswith("bsrnet") else specs.scunet_spec(cfg)
+    W = synth_state_dict(spec, 0, prefix=name.split("_")[0] + ".", gain=gain)
+    x = torch.tensor(np.random.RandomState(17).rand(*shape), dtype=torch.float32)
+    return cfg, W, x
+
+
+# end-to-end cases of BSRNetPipeline / SCUNetPipeline on the tiny ControlLDM: name -> (cleaner, lq spec, run kwargs)
+CLEANER_PIPELINES = {
+    "bsrnet_x4": ("bsrnet_tiny", (21, 1, 128, 128), dict(steps=3, seed=11, upscale=4.0)),
+    "bsrnet_x4_tiled": ("bsrnet_tiny", (22, 1, 160, 192), dict(steps=2, seed=11, upscale=4.0, cleaner_tiled=True,
+                                                               cleaner_tile=128, cleaner_stride=64)),
+    "bsrnet_x2_small": ("bsrnet_tiny", (23, 1, 96, 120), dict(steps=2, seed=11, upscale=2.0)),
+    "scunet": ("scunet_tiny", (24, 1, 512, 512), dict(steps=3, seed=11)),
+    "scunet_tiled_small": ("scunet_tiny", (25, 1, 320, 384), dict(steps=2, seed=11, cleaner_tiled=True, cleaner_tile=256,
+                                                                  cleaner_stride=128)),
+}
+
+
 def quiet():
     return contextlib.redirect_stdout(io.StringIO())
 

@@ -4,6 +4,7 @@
     python -m oracle.make_golden tiny            # seconds..minutes
     python -m oracle.make_golden tiny_options    # option paths of Pipeline.run on the tiny config
     python -m oracle.make_golden host_tables     # schedules / tile windows / blend weights from the reference's functions
+    python -m oracle.make_golden cleaners        # BSRNet / SCUNet modules (tiny + shipped configs) and their pipelines (tiny)
     python -m oracle.make_golden full_modules    # full-size nets, module level (a few minutes)
     python -m oracle.make_golden full_pipeline   # 1x512x512, 50 spaced steps + CFG (≈10 min on 8 cores)
     python -m oracle.make_golden full_configs    # BASELINE configs at full size: C2 (batch 2, spaced 50), C3 (batch 2,
@@ -65,6 +66,43 @@ OPTION_CASES = {
     "cleaner_tiled": ((9, 1, 600, 712), dict(steps=3, sampler="spaced", seed=5, cleaner_tiled=True)),
     "small_upsized": ((13, 1, 300, 256), dict(steps=3, sampler="spaced", seed=5)),
 }
+
+
+@torch.no_grad()
+def gen_cleaners(R):
+    """BSRNet / SCUNet: module outputs of the reference's RRDBNet / SCUNet (tiny + shipped configs) and
+    end-to-end BSRNetPipeline / SCUNetPipeline runs on the tiny ControlLDM.  Also asserts oracle == reference (exact)."""
+    from diffbir_amd import configs
+    from diffbir.model.bsrnet import RRDBNet
+    from diffbir.model.scunet import SCUNet
+    from diffbir.pipeline import BSRNetPipeline, SCUNetPipeline
+    from . import nets
+    g, mods = {}, {}
+    for name in cases.CLEANERS:
+        cfg, W, x = cases.cleaner_case(name)
+        with cases.quiet():
+            m = (RRDBNet if name.startswith("bsrnet") else SCUNet)(**cfg).eval()
+        m.load_state_dict(W, strict=True)
+        y = m(x)
+        o = (nets.rrdbnet_forward if name.startswith("bsrnet") else nets.scunet_forward)(W, cfg, x)
+        assert torch.equal(o, y) or (o - y).abs().max() < 1e-5 * y.abs().max(), name
+        g[name] = y.numpy()
+        mods[name] = m
+        print(name, y.shape, float(y.abs().max()))
+    cldm, _, diff, _ = build_reference(R, "tiny", configs.get("DIFFUSION_V21"))
+    for name, (cleaner, lqspec, kw) in cases.CLEANER_PIPELINES.items():
+        if cleaner.startswith("bsrnet"):
+            pipe = BSRNetPipeline(mods[cleaner], cldm, diff, None, "cpu", kw["upscale"])
+        else:
+            pipe = SCUNetPipeline(mods[cleaner], cldm, diff, None, "cpu")
+        torch.manual_seed(kw["seed"])
+        with cases.quiet():
+            g["pipe_" + name] = pipe.run(
+                cases.make_lq(*lqspec), kw["steps"], 1.0, kw.get("cleaner_tiled", False), kw.get("cleaner_tile", 512),
+                kw.get("cleaner_stride", 256), False, 256, False, 256, False, 512, 256, "", cases.NEG_PROMPT, 4.0, "noise",
+                "spaced", 0, False, 0, 0, 300, 1, 1, 1)
+        print(name, g["pipe_" + name].shape)
+    np.savez_compressed(os.path.join(OUT, "cleaners.npz"), **g)
 
 
 @torch.no_grad()
@@ -419,5 +457,7 @@ if __name__ == "__main__":
         gen_ref_lowp(R)
     elif what == "tokenizer":
         gen_tokenizer(R)
+    elif what == "cleaners":
+        gen_cleaners(R)
     elif what == "full_configs":
         gen_full_configs(R, only=sys.argv[2:] or None)

@@ -238,6 +238,21 @@ def add_scaled(a, b, s, out=None):
     return out
 
 
+def space_to_depth2(x):
+    B, H, W, C = x.shape
+    return x.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C).contiguous()
+
+
+def depth_to_space2(x, out=None):
+    B, h, w, C4 = x.shape
+    C = C4 // 4
+    y = x.reshape(B, h, w, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, C)
+    if out is None:
+        return y.contiguous()
+    out.copy_(y)
+    return out
+
+
 def nchw_to_nhwc(src0, src1, cpad, dtype, scale=1.0, shift=0.0):
     src = src0 if src1 is None else torch.cat([src0, src1], dim=1)
     B, C, H, W = src.shape
@@ -337,6 +352,7 @@ def f32_nchw_to_u8_nhwc(src):
 
 _NAMES = ["linear", "linear_t", "conv3x3", "bmm_nt", "attention", "window_attention", "groupnorm", "groupnorm_stats",
           "groupnorm_apply", "layernorm", "clip_embed", "add_layernorm_f32", "causal_attention",
+          "space_to_depth2", "depth_to_space2",
           "softmax_rows_", "add_scaled", "nchw_to_nhwc", "nhwc_to_nchw", "pixel_unshuffle", "timestep_embedding",
           "lincomb4", "spaced_step", "tile_gather", "tile_accumulate", "tile_accumulate_partial", "tile_normalize",
           "u8_to_f32_nchw", "wavelet_blur", "colorfix",

@@ -97,3 +97,33 @@ def run_sampler_case(pipe, name):
 def rel_err(a, b):
     a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item(), (a - b).abs().max().item()
+
+
+# ---- BSRNet / SCUNet cleaners (goldens: tests/golden/cleaners.npz, oracle/make_golden.py gen_cleaners) ----------------
+def build_cleaner(name: str, device, dtype, raw_dtype=False):
+    """-> (engine module with the seeded weights of oracle.cases.cleaner_case(name), input f32 NCHW)."""
+    from diffbir_amd.model import RRDBNet, SCUNet
+    cfg, W, x = cases.cleaner_case(name)
+    m = (RRDBNet if name.startswith("bsrnet") else SCUNet)(**cfg)
+    m.load_state_dict(W, strict=True)
+    m.to(device)
+    if raw_dtype:
+        m._dtype, m._packed = dtype, False
+    else:
+        m.set_dtype(dtype)
+    return m, x.to(device)
+
+
+def run_cleaner_pipeline(name: str, cldm, diff, device, dtype, raw_dtype=False):
+    """The BSRNetPipeline / SCUNetPipeline run of oracle.cases.CLEANER_PIPELINES[name] on the engine."""
+    from diffbir_amd.pipeline import BSRNetPipeline, SCUNetPipeline
+    cleaner, lqspec, kw = cases.CLEANER_PIPELINES[name]
+    m, _ = build_cleaner(cleaner, device, dtype, raw_dtype)
+    if cleaner.startswith("bsrnet"):
+        pipe = BSRNetPipeline(m, cldm, diff, None, str(device), kw["upscale"])
+    else:
+        pipe = SCUNetPipeline(m, cldm, diff, None, str(device))
+    pipe.randn = cases.NoiseStream(kw["seed"])
+    return pipe.run(cases.make_lq(*lqspec), kw["steps"], 1.0, kw.get("cleaner_tiled", False), kw.get("cleaner_tile", 512),
+                    kw.get("cleaner_stride", 256), False, 256, False, 256, False, 512, 256, "", cases.NEG_PROMPT, 4.0,
+                    "noise", "spaced", 0, False, 0, 0, 300, 1, 1, 1)

@@ -10,7 +10,8 @@ import torch
 
 from oracle import cases
 from tests import emu_ops
-from tests.helpers import OPTION_CASES, SAMPLER_CASES, build_engine, rel_err, run_option_case, run_pipe, run_sampler_case
+from tests.helpers import (OPTION_CASES, SAMPLER_CASES, build_cleaner, build_engine, rel_err, run_cleaner_pipeline,
+                           run_option_case, run_pipe, run_sampler_case)
 
 
 @pytest.fixture()
@@ -218,3 +219,25 @@ def test_cfg_pair_shared_prefix_is_exact(engine, monkeypatch):
         cldm(bad, t, dict(c_txt=c_txt, c_img=c_img, cfg_pair=(G, bs)))
     monkeypatch.setattr(unet_mod, "SHARE_CFG_PREFIX", False)
     assert rel_err(cldm(x, t, dict(c_txt=c_txt, c_img=c_img, cfg_pair=(G, bs))), plain.numpy())[0] == 0.0
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("name", sorted(cases.CLEANERS))
+def test_cleaner_modules_vs_reference_golden(monkeypatch, golden_dir, name):
+    """Host-side orchestration of the BSRNet (dense-block column buffers, zero-padded weights) and SCUNet (split 1x1,
+    window-attention table layout, 2x2 stride-2 convs as GEMMs) engines against the reference's own module outputs."""
+    emu_ops.install(monkeypatch)
+    m, x = build_cleaner(name, torch.device("cpu"), torch.float32, raw_dtype=True)
+    ref = np.load(os.path.join(golden_dir, "cleaners.npz"))[name]
+    assert rel_err(m(x), ref)[0] < 1e-4
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("name", sorted(cases.CLEANER_PIPELINES))
+def test_cleaner_pipelines_vs_reference_golden(monkeypatch, golden_dir, name):
+    emu_ops.install(monkeypatch)
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", torch.device("cpu"), torch.float32, raw_dtype=True)
+    out = run_cleaner_pipeline(name, cldm, pipe.diffusion, torch.device("cpu"), torch.float32, raw_dtype=True)
+    ref = np.load(os.path.join(golden_dir, "cleaners.npz"))["pipe_" + name]
+    assert out.shape == ref.shape and out.dtype == np.uint8
+    assert cases.psnr_u8(out, ref) > 60.0

@@ -626,7 +626,9 @@ def test_attention_peaked_softmax(dtype, attn_variant):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,C,heads,shift", [(2, 16, 16, 180, 6, 0), (2, 16, 24, 180, 6, 4), (1, 8, 8, 60, 6, 4),
-                                                  (1, 64, 64, 180, 6, 4)])
+                                                  (1, 64, 64, 180, 6, 4),
+                                                  # SCUNet: head_dim 32, 1 / 2 / 8 heads, shift = window / 2
+                                                  (2, 16, 24, 32, 1, 4), (1, 24, 16, 64, 2, 0), (1, 8, 16, 256, 8, 4)])
 def test_window_attention(B, H, W, C, heads, shift, dtype):
     ld = (3 * C + 7) // 8 * 8
     Cp = (C + 15) // 16 * 16
@@ -722,6 +724,17 @@ def test_causal_attention(B, H, L, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ elementwise & co
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_block2x2_space_depth(dtype):
+    x = rnd(2, 6, 10, 96, dtype=dtype)
+    a = ops.space_to_depth2(x[..., 16:48])                       # strided source (column slice)
+    assert torch.equal(a, emu.space_to_depth2(x[..., 16:48]))    # pure data movement: exact
+    assert torch.equal(ops.depth_to_space2(a), x[..., 16:48].contiguous())
+    wide = torch.zeros(2, 6, 10, 64, dtype=dtype, device=DEV)
+    ops.depth_to_space2(a, out=wide[..., 32:])                   # strided destination
+    assert torch.equal(wide[..., 32:], x[..., 16:48]) and float(wide[..., :32].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_and_elementwise(dtype):
     a, b = rnd(2, 9, 7, 96, dtype=dtype), rnd(2, 9, 7, 160, dtype=dtype, seed=1)

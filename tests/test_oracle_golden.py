@@ -115,3 +115,13 @@ def test_pipeline_options_match_reference_golden(tiny, gm, golden_dir, name):
     assert out.shape == ref.shape
     diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("name", sorted(cases.CLEANERS))
+def test_cleaners_match_reference_golden(golden_dir, name):
+    """oracle RRDBNet / SCUNet restatements == outputs of the reference's own modules (tests/golden/cleaners.npz)."""
+    g = np.load(os.path.join(golden_dir, "cleaners.npz"))
+    cfg, W, x = cases.cleaner_case(name)
+    fn = nets.rrdbnet_forward if name.startswith("bsrnet") else nets.scunet_forward
+    _close(fn(W, cfg, x), g[name], 2e-5)

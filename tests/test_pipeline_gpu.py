@@ -266,3 +266,35 @@ def test_tiled_vae_vs_reference_golden(golden_dir):
     psnr = cases.psnr_u8(out, g["pipe_vae_tiled"])
     REPORT["tiny_pipe_vae_tiled_fp16"] = psnr
     assert psnr >= 45.0, psnr
+
+
+# ---- BSRNet / SCUNet cleaners ----------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", sorted(cases.CLEANERS))
+@torch.no_grad()
+def test_cleaner_modules_vs_reference_golden(golden_dir, name, dtype):
+    """RRDBNet / SCUNet on the HIP kernels vs the outputs of the reference's own modules (same seeded weights)."""
+    from tests.helpers import build_cleaner
+    m, x = build_cleaner(name, _dev(), dtype)
+    ref = np.load(os.path.join(golden_dir, "cleaners.npz"))[name]
+    err = rel_err(m(x), ref)
+    REPORT[f"cleaner_{name}_{dtype}"] = err[0]
+    print(name, dtype, f"{err[0]:.2e}")
+    assert err[0] < MOD_TOL[dtype], err
+
+
+@pytest.mark.parametrize("name", sorted(cases.CLEANER_PIPELINES))
+@torch.no_grad()
+def test_cleaner_pipelines_vs_reference_golden(golden_dir, name):
+    """BSRNetPipeline (x4 cleaner on the LQ image, tiled with scale 4, bicubic resize) / SCUNetPipeline end to end, fp16,
+    against the reference's CPU-fp32 output: north_star tolerance 45 dB."""
+    from tests.helpers import run_cleaner_pipeline
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    out = run_cleaner_pipeline(name, cldm, pipe.diffusion, dev, torch.float16)
+    ref = np.load(os.path.join(golden_dir, "cleaners.npz"))["pipe_" + name]
+    assert out.shape == ref.shape and out.dtype == np.uint8
+    psnr = cases.psnr_u8(out, ref)
+    REPORT[f"cleaner_pipe_{name}"] = psnr
+    print(name, f"{psnr:.2f} dB")
+    assert psnr >= 45.0, psnr
