@@ -20,7 +20,7 @@ void dbir_attention_set_variant(int v);  // attention.hip
 extern "C" int dbir_set_option(int key, int value) {
   switch (key) {
     case DBIR_OPT_ATTN_VARIANT:
-      DBIR_CHECK_ARG(value == 2 || value == 3, "dbir_set_option: attention variant must be 2 (default) or 3 (generic kernel only)");
+      DBIR_CHECK_ARG(value >= 2 && value <= 5, "dbir_set_option: attention variant must be 2 (default), 3 (generic kernel only), 4 / 5 (generic kernel at 4 / 3 waves per SIMD)");
       dbir_attention_set_variant(value);
       return DBIR_OK;
   }

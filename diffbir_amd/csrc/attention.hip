@@ -34,8 +34,8 @@ constexpr int V_LD = 64 + 4;  // V^T tile row (halfs): 136 B -> conflict-free ds
 //     ragged last tile, and the O / l rescale is skipped while the running max grows by less than 2^8 for every
 //     row of the wave (guide T13; P is then bounded by 256, exact in f32 and well inside f16 / bf16 range; the
 //     decision precedes the tile's exponentials and its P.V, the textbook order).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn2_kernel(const u16* __restrict__ Q, long long q_bs, long long ldq,
+template <typename T, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__ Q, long long q_bs, long long ldq,
                                                        const u16* __restrict__ K, long long k_bs, long long ldk,
                                                        const u16* __restrict__ Vt, long long vt_bs, long long ldvt,
                                                        u16* __restrict__ O, long long o_bs, long long ldo, int H,
@@ -398,7 +398,8 @@ int g_attn_variant = 2;
 
 }  // namespace
 
-// A/B switch (dbir_set_option): 2 = default (cross kernel for Lk <= 96, generic otherwise), 3 = generic kernel always
+// A/B switch (dbir_set_option): 2 = default (cross kernel for Lk <= 96, generic otherwise), 3 = generic kernel always,
+// 4 / 5 = default dispatch with the generic kernel compiled for 4 / 3 resident waves per SIMD
 void dbir_attention_set_variant(int v) { g_attn_variant = v; }
 
 extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, long long ldq, const void* K,
@@ -438,12 +439,22 @@ extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, lon
   }
   DBIR_CHECK_ARG((long long)cdiv(Lq, 128) * B * H < 2147483647LL, "dbir_attention: grid too large");
   const dim3 grid1((unsigned)(cdiv(Lq, 128) * B * H));
-  if (dtype == DBIR_F16)
-    hipLaunchKernelGGL((attn2_kernel<F16>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
-                       k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
-  else
-    hipLaunchKernelGGL((attn2_kernel<BF16>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,
-                       k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
+#define ATTN2_LAUNCH(TT, OCC)                                                                                          \
+  hipLaunchKernelGGL((attn2_kernel<TT, OCC>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,    \
+                     k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2)
+  // register budget variants (A/B through dbir_set_option): 2 waves / SIMD guaranteed (the compiler lands on 134 VGPRs =
+  // 3 resident), 4: capped at 128 VGPRs = 4 resident, 5: 3 resident by construction
+  const int occ = g_attn_variant == 4 ? 4 : (g_attn_variant == 5 ? 3 : 2);
+  if (dtype == DBIR_F16) {
+    if (occ == 4) ATTN2_LAUNCH(F16, 4);
+    else if (occ == 3) ATTN2_LAUNCH(F16, 3);
+    else ATTN2_LAUNCH(F16, 2);
+  } else {
+    if (occ == 4) ATTN2_LAUNCH(BF16, 4);
+    else if (occ == 3) ATTN2_LAUNCH(BF16, 3);
+    else ATTN2_LAUNCH(BF16, 2);
+  }
+#undef ATTN2_LAUNCH
   DBIR_CHECK_LAUNCH("dbir_attention");
   return DBIR_OK;
 }
