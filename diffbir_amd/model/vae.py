@@ -169,35 +169,67 @@ class AutoencoderKL(NativeModule):
                 ins.append([max(0, box[0] - pad), min(w, box[1] + pad), max(0, box[2] - pad), min(h, box[3] + pad)])
         return ins, outs
 
-    def _gn_tiles(self, tiles: List[T], gn, silu: bool) -> List[T]:
+    # ---- tile sharding (one process per GPU; diffbir_amd.parallel.enable_tile_sharding) --------------------------
+    # tile_shard = (rank, world): this rank runs tiles rank::world of every tiled encode / decode.  The only cross-tile
+    # couplings of the algorithm are the averaged GroupNorm statistics (2*groups floats per sample and layer) and the
+    # final paste: the statistics are summed over ranks with `tile_all_reduce` (a tiny all-reduce per GroupNorm layer),
+    # the pasted result (disjoint regions, zeros elsewhere) with one all-reduce at the end.
+    tile_shard = None
+    tile_all_reduce = None
+
+    class _Tiles:
+        """Bookkeeping of one tiled pass: global indices of the tiles held by this rank and the CURRENT (h, w) of every
+        tile of the image (all ranks track all shapes: the GroupNorm weights are pixel counts of all tiles)."""
+
+        def __init__(self, hw: List[tuple], shard, reduce):
+            self.hw = list(hw)
+            n = len(hw)
+            self.idx = list(range(n)) if shard is None else list(range(shard[0], n, shard[1]))
+            self.reduce = reduce if shard is not None else None
+
+        def scale(self, f):
+            self.hw = [f(h, w) for h, w in self.hw]
+
+    def _gn_tiles(self, tiles: List[T], gn, silu: bool, tc: "AutoencoderKL._Tiles") -> List[T]:
         """GroupNorm over a list of tiles with pixel-weighted averaged statistics (tilevae.py:241-279)."""
-        if len(tiles) == 1:
+        if len(tc.hw) == 1 and tc.reduce is None:
             return [ops.groupnorm(tiles[0], gn[0], gn[1], 1e-6, silu)]
-        stats = [ops.groupnorm_stats(t) for t in tiles]
-        px = torch.tensor([t.shape[1] * t.shape[2] for t in tiles], dtype=torch.float32, device=tiles[0].device)
+        dev = self._device
+        px = torch.tensor([h * w for h, w in tc.hw], dtype=torch.float32, device=dev)
         wgt = px / px.max()
         wgt = wgt / wgt.sum()
-        mv = (torch.stack(stats, dim=0) * wgt[:, None, None]).sum(dim=0).contiguous()
+        if tiles:
+            assert all(tuple(t.shape[1:3]) == tuple(tc.hw[i]) for t, i in zip(tiles, tc.idx))
+            stats = torch.stack([ops.groupnorm_stats(t) for t in tiles], dim=0)
+            mv = (stats * wgt[tc.idx][:, None, None]).sum(dim=0).contiguous()
+        else:   # more ranks than tiles: this rank only takes part in the reductions
+            mv = torch.zeros((self._tile_batch, 64), dtype=torch.float32, device=dev)
+        if tc.reduce is not None:
+            mv = tc.reduce(mv)
         return [ops.groupnorm_apply(t, gn[0], gn[1], mv, 1e-6, silu) for t in tiles]
 
-    def _res_tiles(self, r: _VRes, tiles: List[T]) -> List[T]:
-        h = self._gn_tiles(tiles, r.gn1, True)
+    def _res_tiles(self, r: _VRes, tiles: List[T], tc) -> List[T]:
+        h = self._gn_tiles(tiles, r.gn1, True, tc)
         h = [ops.conv3x3(t, r.conv1) for t in h]
-        h = self._gn_tiles(h, r.gn2, True)
+        h = self._gn_tiles(h, r.gn2, True, tc)
         skip = tiles if r.nin is None else [ops.linear(t, r.nin) for t in tiles]
         return [ops.conv3x3(t, r.conv2, residual=sk) for t, sk in zip(h, skip)]
 
-    def _attn_tiles(self, a: dict, tiles: List[T]) -> List[T]:
-        hn = self._gn_tiles(tiles, a["gn"], False)
+    def _attn_tiles(self, a: dict, tiles: List[T], tc) -> List[T]:
+        hn = self._gn_tiles(tiles, a["gn"], False, tc)
         return [self._attn_core(a, n, x) for n, x in zip(hn, tiles)]
 
-    def _paste(self, tiles: List[T], ins, outs, is_decoder: bool, B: int, H: int, W: int) -> T:
-        """crop_valid_region + write into the result (tilevae.py:218-229, 545-547); NHWC."""
-        res = torch.zeros((B, H, W, tiles[0].shape[-1]), dtype=tiles[0].dtype, device=tiles[0].device)
-        for t, ib, ob in zip(tiles, ins, outs):
+    def _paste(self, tiles: List[T], ins, outs, is_decoder: bool, B: int, H: int, W: int, tc, channels: int, dtype) -> T:
+        """crop_valid_region + write into the result (tilevae.py:218-229, 545-547); NHWC.  Sharded: every rank pastes
+        its tiles into zeros and the (disjoint) partial results are summed."""
+        res = torch.zeros((B, H, W, channels), dtype=torch.float32 if tc.reduce is not None else dtype, device=self._device)
+        for t, i in zip(tiles, tc.idx):
+            ib, ob = ins[i], outs[i]
             pb = [v * 8 if is_decoder else v // 8 for v in ib]
             m = [ob[k] - pb[k] for k in range(4)]
             res[:, ob[2]:ob[3], ob[0]:ob[1]] = t[:, m[2]:t.shape[1] + m[3], m[0]:t.shape[2] + m[1]]
+        if tc.reduce is not None:
+            res = tc.reduce(res).to(dtype)
         return res
 
     def encode_moments_tiled(self, x: T, tile_size: int, in_scale: float = 1.0, in_shift: float = 0.0) -> T:
@@ -209,21 +241,24 @@ class AutoencoderKL(NativeModule):
             print("[Tiled VAE]: the input size is tiny and unnecessary to tile.")
             return self.encode_moments(x, in_scale, in_shift)
         ins, outs = self.split_tiles(H, W, tile_size, pad, False)
+        tc = self._Tiles([(b[3] - b[2], b[1] - b[0]) for b in ins], self.tile_shard, self.tile_all_reduce)
+        self._tile_batch = B
         x = x.float()
-        t = [ops.nchw_to_nhwc(x[:, :, b[2]:b[3], b[0]:b[1]].contiguous(), None, 8, self._dtype, in_scale, in_shift)
-             for b in ins]
+        t = [ops.nchw_to_nhwc(x[:, :, ins[i][2]:ins[i][3], ins[i][0]:ins[i][1]].contiguous(), None, 8, self._dtype, in_scale,
+                              in_shift) for i in tc.idx]
         t = [ops.conv3x3(v, self.e_conv_in) for v in t]
         for blocks, ds in self.e_down:
             for r in blocks:
-                t = self._res_tiles(r, t)
+                t = self._res_tiles(r, t, tc)
             if ds is not None:
                 t = [ops.conv3x3(v, ds, stride=2, pad=0, out_hw=(v.shape[1] // 2, v.shape[2] // 2)) for v in t]
-        t = self._res_tiles(self.e_mid[0], t)
-        t = self._attn_tiles(self.e_mid[1], t)
-        t = self._res_tiles(self.e_mid[2], t)
-        t = self._gn_tiles(t, self.e_norm_out, True)
+                tc.scale(lambda h, w: (h // 2, w // 2))
+        t = self._res_tiles(self.e_mid[0], t, tc)
+        t = self._attn_tiles(self.e_mid[1], t, tc)
+        t = self._res_tiles(self.e_mid[2], t, tc)
+        t = self._gn_tiles(t, self.e_norm_out, True, tc)
         t = [ops.conv3x3(v, self.e_conv_out) for v in t]
-        h = self._paste(t, ins, outs, False, B, H // 8, W // 8)
+        h = self._paste(t, ins, outs, False, B, H // 8, W // 8, tc, self.e_conv_out.n_out, self._dtype)
         return ops.linear(h, self.quant, out_f32=True)
 
     def decode_tiled(self, z: T, tile_size: int, in_scale: float = 1.0) -> T:
@@ -237,19 +272,22 @@ class AutoencoderKL(NativeModule):
         h = ops.nchw_to_nhwc(z.float().contiguous(), None, 8, self._dtype, in_scale, 0.0)
         h = ops.linear(h, self.post_quant)
         ins, outs = self.split_tiles(H, W, tile_size, pad, True)
-        t = [h[:, b[2]:b[3], b[0]:b[1]].contiguous() for b in ins]
+        tc = self._Tiles([(b[3] - b[2], b[1] - b[0]) for b in ins], self.tile_shard, self.tile_all_reduce)
+        self._tile_batch = B
+        t = [h[:, ins[i][2]:ins[i][3], ins[i][0]:ins[i][1]].contiguous() for i in tc.idx]
         t = [ops.conv3x3(v, self.d_conv_in) for v in t]
-        t = self._res_tiles(self.d_mid[0], t)
-        t = self._attn_tiles(self.d_mid[1], t)
-        t = self._res_tiles(self.d_mid[2], t)
+        t = self._res_tiles(self.d_mid[0], t, tc)
+        t = self._attn_tiles(self.d_mid[1], t, tc)
+        t = self._res_tiles(self.d_mid[2], t, tc)
         for blocks, us in self.d_up:
             for r in blocks:
-                t = self._res_tiles(r, t)
+                t = self._res_tiles(r, t, tc)
             if us is not None:
                 t = [ops.conv3x3(v, us, upsample=True) for v in t]
-        t = self._gn_tiles(t, self.d_norm_out, True)
+                tc.scale(lambda h, w: (2 * h, 2 * w))
+        t = self._gn_tiles(t, self.d_norm_out, True, tc)
         t = [ops.conv3x3(v, self.d_conv_out, out_f32=True) for v in t]
-        o = self._paste(t, ins, outs, True, B, H * 8, W * 8)
+        o = self._paste(t, ins, outs, True, B, H * 8, W * 8, tc, self.d_conv_out.n_out, torch.float32)
         return ops.nhwc_to_nchw(o, self.out_ch)
 
     # ------------------------------------------------------------------ API
