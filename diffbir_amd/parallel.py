@@ -155,18 +155,26 @@ def gather_batch(local: np.ndarray, batch: int, ctx: DistContext, dst: int = 0) 
 
 
 def enable_tile_sharding(pipe, ctx: DistContext, seed: Optional[int] = 231, check_every: int = 0) -> None:
-    """Tiled sampling evaluates tiles rank::world on this rank and all-reduces the partial sums.
+    """Tiled sampling evaluates tiles rank::world on this rank and all-reduces the partial sums; the tiled VAE of
+    `pipe.cldm` (model/vae.py `tile_shard`) is sharded over the same ranks.
 
     Every rank performs the sampler update redundantly, so every rank MUST draw the same x_T and per-step noise: unless
     the caller already installed a shared noise source (`pipe.randn`), an identically seeded device generator is
     installed here (`seed=None` leaves the pipeline alone — then the caller is responsible).  `check_every = n > 0`
     additionally all-reduces a checksum of the blended prediction every n evaluations and raises if the ranks' inputs
     have diverged (debug aid: one extra 8-byte all-reduce)."""
+    vae = getattr(getattr(pipe, "cldm", None), "vae", None)
     if ctx.world <= 1:
         pipe.tile_shard, pipe.tile_all_reduce = None, None
+        if vae is not None:
+            vae.tile_shard, vae.tile_all_reduce = None, None
         return
     pipe.tile_shard = (ctx.rank, ctx.world)
     reduce = all_reduce_sum(ctx)
+    if vae is not None:
+        # the tiled VAE (--vae_encoder_tiled / --vae_decoder_tiled) shards its tiles the same way: per GroupNorm layer one
+        # all-reduce of the tile-averaged statistics (2 * 32 floats per sample), one all-reduce of the pasted result
+        vae.tile_shard, vae.tile_all_reduce = (ctx.rank, ctx.world), reduce
     if check_every > 0:
         state = {"n": 0}
 

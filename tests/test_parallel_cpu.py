@@ -86,6 +86,13 @@ def _worker(rank: int, world: int, port: int, outdir: str):
         lq = cases.make_lq(9, 1, 600, 712)
         out = pipe.run(lq, *args(3, "spaced", tiled=True))
         np.save(os.path.join(outdir, f"tiled_{rank}.npy"), out)
+
+        # ---- the tiled VAE is sharded over the same ranks (golden: tiny_tiled_vae.npz, the reference's VAEHook)
+        assert cldm.vae.tile_shard == (rank, world)
+        x = torch.tensor(cases.make_lq(31, 1, 608, 712)).float().div(255).permute(0, 3, 1, 2).contiguous()
+        enc = cldm.vae_encode(x * 2 - 1, sample=False, tiled=True, tile_size=256)
+        dec = cldm.vae_decode(cases.NoiseStream(9)((1, 4, 76, 89)), tiled=True, tile_size=32)
+        np.savez(os.path.join(outdir, f"vae_{rank}.npz"), enc=enc.numpy(), dec=dec.numpy())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -104,3 +111,9 @@ def test_world2_gloo_matches_reference_golden(golden_dir):
         assert np.array_equal(t0, t1), "ranks must agree after the all-reduce (redundant sampler update)"
         # the parallel reduction changes the f32 summation order of the tile blend: tolerance, not bit-exactness
         assert cases.psnr_u8(t0, ref["spaced3_tiled_v21"]) > 55.0
+        v0, v1 = (np.load(os.path.join(outdir, f"vae_{r}.npz")) for r in range(2))
+        gv = np.load(os.path.join(golden_dir, "tiny_tiled_vae.npz"))
+        for k, gk in (("enc", "enc_tiled_256"), ("dec", "dec_tiled_32")):
+            assert np.array_equal(v0[k], v1[k]), "ranks must hold the same tiled-VAE result after the all-reduce"
+            err = np.linalg.norm(v0[k] - gv[gk]) / np.linalg.norm(gv[gk])
+            assert err < 2e-4, (k, err)
