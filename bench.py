@@ -63,6 +63,11 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per pass (default: the config's)")
     ap.add_argument("--sampler-steps", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["fp16", "bf16"])
+    ap.add_argument("--vae-tiled", default="auto", choices=["auto", "on", "off"],
+                    help="the reference's --vae_encoder_tiled / --vae_decoder_tiled (tile 256).  auto: on for the tiled "
+                         "configs when N > 1 (its tiles are then sharded over the ranks like the diffusion tiles; untiled, "
+                         "every rank would repeat the whole VAE), off otherwise (one MI355X holds the untiled VAE of a "
+                         "4096x4096 image: exact query-chunked attention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selftest", action="store_true",
@@ -139,8 +144,8 @@ def build_engine(device, dtype, ctx=None):
     return SwinIRPipeline(swin, cldm, diff, None, str(device)), cldm, swin
 
 
-def run_once(pipe, lq, sampler_steps, sampler="spaced", tiled=False):
-    return pipe.run(lq, sampler_steps, 1.0, False, 512, 256, False, 256, False, 256, tiled, 512, 256, "", NEG, 4.0,
+def run_once(pipe, lq, sampler_steps, sampler="spaced", tiled=False, vae_tiled=False):
+    return pipe.run(lq, sampler_steps, 1.0, False, 512, 256, vae_tiled, 256, vae_tiled, 256, tiled, 512, 256, "", NEG, 4.0,
                     "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
 
 
@@ -308,8 +313,11 @@ def main():
         else:
             torch.manual_seed(231 + rank)
 
+        vae_tiled = args.vae_tiled == "on" or (args.vae_tiled == "auto" and cfg["tiled"] and world > 1)
+        extra["vae_tiled"] = vae_tiled
+
         def run_step():
-            return run_once(pipe, lq_dev, args.sampler_steps, cfg["sampler"], cfg["tiled"])
+            return run_once(pipe, lq_dev, args.sampler_steps, cfg["sampler"], cfg["tiled"], vae_tiled)
 
     def barrier():
         sync()
