@@ -143,20 +143,34 @@ def test_specs_match_reference_state_dicts():
         diff = {k: (ref[k], mine[k]) for k in ref if ref[k] != mine[k]}
         assert not diff, (what, list(diff.items())[:4])
 
+    import contextlib
     from oracle import cases
     for cfg_name in ("tiny", "full"):
         cldm_cfg, swin_cfg = cases.get_cfgs(cfg_name)
+        # full size: build the reference modules on the meta device (shapes only — real initialisation of 1.3 G parameters
+        # takes minutes on CPU and the values are irrelevant here)
+        meta = (lambda: torch.device("meta")) if cfg_name == "full" else contextlib.nullcontext
         with cases.quiet():
-            cmp(cn.ControlledUnetModel(**cldm_cfg["unet_cfg"]), specs.unet_spec(cldm_cfg["unet_cfg"]), f"unet {cfg_name}")
-            cmp(cn.ControlNet(**cldm_cfg["controlnet_cfg"]), specs.controlnet_spec(cldm_cfg["controlnet_cfg"]),
-                f"controlnet {cfg_name}")
-            cmp(vae.AutoencoderKL(**cldm_cfg["vae_cfg"]), specs.vae_spec(cldm_cfg["vae_cfg"]), f"vae {cfg_name}")
+            with meta():
+                unet = cn.ControlledUnetModel(**cldm_cfg["unet_cfg"])
+                cnet = cn.ControlNet(**cldm_cfg["controlnet_cfg"])
+                ae = vae.AutoencoderKL(**cldm_cfg["vae_cfg"])
+            cmp(unet, specs.unet_spec(cldm_cfg["unet_cfg"]), f"unet {cfg_name}")
+            cmp(cnet, specs.controlnet_spec(cldm_cfg["controlnet_cfg"]), f"controlnet {cfg_name}")
+            cmp(ae, specs.vae_spec(cldm_cfg["vae_cfg"]), f"vae {cfg_name}")
             cmp(R.SwinIR(**swin_cfg), specs.swinir_spec(swin_cfg), f"swinir {cfg_name}",
                 ignore=("attn_mask", "relative_position_index"))
     cldm_cfg, _ = cases.get_cfgs("tiny")
     clip = importlib.import_module("diffbir.model.clip")
+    bsr = importlib.import_module("diffbir.model.bsrnet")
+    scu = importlib.import_module("diffbir.model.scunet")
+    from diffbir_amd import configs
     with cases.quiet():
         cmp(clip.FrozenOpenCLIPEmbedder(**cldm_cfg["clip_cfg"]), specs.clip_text_spec(cldm_cfg["clip_cfg"]), "clip tiny")
+        for name in ("TINY_BSRNET", "FULL_BSRNET"):
+            cmp(bsr.RRDBNet(**configs.get(name)), specs.bsrnet_spec(configs.get(name)), name)
+        for name in ("TINY_SCUNET", "FULL_SCUNET"):
+            cmp(scu.SCUNet(**configs.get(name)), specs.scunet_spec(configs.get(name)), name)
 
 
 # ------------------------------------------------------------------------------------------------ tokenizer
