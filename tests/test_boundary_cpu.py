@@ -246,3 +246,52 @@ def test_cli_flag_surface_equals_reference():
         assert act.type == kw.get("type"), flag
         assert bool(act.required) == bool(kw.get("required", False)), flag
     assert len(seen) >= 40 and set(ours) == seen, sorted(set(ours) ^ seen)
+
+
+def test_v2_loops_select_bsrnet_and_scunet(monkeypatch):
+    """reference bsr_loop.py:20-52 / bid_loop.py:20-48: `--version v2` selects the BSRNet (RRDBNet) / SCUNet stage-1 model,
+    its checkpoint and BSRNetPipeline(upscale) / SCUNetPipeline; v1 / v2.1 keep SwinIR; BSRNet input is NOT pre-upscaled."""
+    import types
+
+    import numpy as np
+    from PIL import Image
+
+    from diffbir_amd import inference as inf
+    from diffbir_amd.inference import bid_loop, bsr_loop
+    from diffbir_amd.model import RRDBNet, SCUNet
+    from diffbir_amd.model import specs as sp
+    from diffbir_amd.pipeline import BSRNetPipeline, SCUNetPipeline, SwinIRPipeline
+    tiny = {"bsrnet": ("diffbir.model.RRDBNet", "TINY_BSRNET", sp.bsrnet_spec),
+            "scunet": ("diffbir.model.SCUNet", "TINY_SCUNET", sp.scunet_spec),
+            "swinir": ("diffbir.model.SwinIR", "TINY_SWINIR", sp.swinir_spec)}
+    asked = []
+
+    def fake_config(name):
+        return dict(target=tiny[name][0], params=configs.get(tiny[name][1]))
+
+    def fake_weights(url):
+        asked.append(url)
+        kind = "bsrnet" if "BSRNet" in url else ("scunet" if "scunet" in url else "swinir")
+        return synth_state_dict(tiny[kind][2](configs.get(tiny[kind][1])), 0)
+
+    for mod in (bsr_loop, bid_loop):
+        monkeypatch.setattr(mod, "load_config", fake_config)
+        monkeypatch.setattr(mod, "load_model_from_url", fake_weights)
+    img = Image.fromarray(np.zeros((20, 30, 3), dtype=np.uint8))
+    for cls, version, model, pipe_cls, url_part, resized in (
+            (inf.BSRInferenceLoop, "v2", RRDBNet, BSRNetPipeline, "BSRNet.pth", False),
+            (inf.BSRInferenceLoop, "v2.1", SwinIR, SwinIRPipeline, "realesrgan", True),
+            (inf.BIDInferenceLoop, "v2", SCUNet, SCUNetPipeline, "scunet_color_real_psnr", True),
+            (inf.BIDInferenceLoop, "v1", SwinIR, SwinIRPipeline, "general_swinir", True)):
+        loop = object.__new__(cls)
+        loop.args = types.SimpleNamespace(version=version, device="cpu", upscale=2)
+        loop.cldm, loop.diffusion, loop.cond_fn = object(), object(), None
+        loop.load_cleaner()
+        loop.load_pipeline()
+        assert isinstance(loop.cleaner, model) and type(loop.pipeline) is pipe_cls, (cls, version)
+        assert url_part in asked[-1], asked[-1]
+        if pipe_cls is BSRNetPipeline:
+            assert loop.pipeline.upscale == 2
+            loop.pipeline.set_output_size((1, 3, 20, 30))
+            assert loop.pipeline.output_size == (40, 60)
+        assert loop.after_load_lq(img).shape == ((40, 60, 3) if resized else (20, 30, 3))
