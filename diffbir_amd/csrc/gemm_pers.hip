@@ -40,7 +40,6 @@ struct PParams {
   int mtiles, ntiles, nk;  // output tiles, K tiles per output tile
   int q, gx;               // tiles / workgroups per XCD
   int a_bytes, w_bytes;    // buffer descriptor extents
-  int phase;               // 0: none; 1 / 2: workgroups (loc >= gx / 2) / (odd loc) start one main-loop time late
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -79,15 +78,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_pers_kernel(const PPar
   const int nmine = xn > loc ? (xn - loc + p.gx - 1) / p.gx : 0;
   if (nmine == 0) return;
   const int nk = p.nk, total = nmine * nk;
-  // Two workgroups share a CU (OCC == 2) and have identical work, so they run in phase: both in the K loop, then both
-  // in the epilogue, and the matrix pipe idles during every epilogue (the GEGLU erf epilogue is as long as a K = 320
-  // main loop).  Starting one of them about one main-loop time late (nk K tiles x 2 k-steps x MI*NJ MFMAs x 32 cycles;
-  // s_sleep counts 64-cycle units) puts its epilogues under the other's MFMAs for the rest of the tile walk.
-  if (OCC == 2 && p.phase != 0) {
-    const bool late = p.phase == 1 ? (loc >= (p.gx >> 1)) : (loc & 1);
-    if (late)
-      for (int i = 0; i < nk; ++i) __builtin_amdgcn_s_sleep(MI * NJ);
-  }
 
   constexpr int OOB = 0x7fffff00;
   const __amdgpu_buffer_rsrc_t a_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.A), 0, p.a_bytes, 0x00020000);
@@ -360,8 +350,6 @@ int launch_pers(const dbir_gemm_desc& dd, hipStream_t s) {
   const int tiles = p.mtiles * p.ntiles;
   p.q = cdiv(tiles, 8);
   p.gx = p.q < 32 * OCC ? p.q : 32 * OCC;
-  static const int phase_env = getenv("DBIR_PERS_PHASE") ? atoi(getenv("DBIR_PERS_PHASE")) : 0;
-  p.phase = phase_env;
   p.a_bytes = (int)((((long long)(dd.M - 1) * dd.lda + dd.K) * 2 + 15) & ~15LL);
   p.w_bytes = (int)((long long)dd.Wrows * dd.Kpad * 2);
   auto kern = &gemm_pers_kernel<T, WM, WN, MI, NJ, STAGES, OCC>;
