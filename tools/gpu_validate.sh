@@ -1,6 +1,7 @@
 #!/bin/bash
 # Full validation on the GPU box (run through gpurun from the repo root): -m gpu suite, smoke, bench (with cpu baseline),
-# rocprofv3 kernel stats, PMC traffic, tiled 2048x2048 timing.  Outputs under gpurun_out/; summaries are copied to profiles/ by hand.
+# rocprofv3 kernel stats, PMC traffic, the other BASELINE configs (c3 / c4 / c5).  Outputs under gpurun_out/; summaries are
+# copied to profiles/ by hand.  tools/gpu_validate_quick.sh = the first four steps only (about 8 GPU-minutes).
 cd "${GRAFT_REPO_ROOT:-.}"
 REPO=$PWD
 mkdir -p gpurun_out
@@ -16,4 +17,4 @@ mkdir -p gpurun_out/prof_f
 echo "rocprof rc=$? t=$(( $(date +%s) - T0 ))s"
 find gpurun_out/prof_f -name "*kernel_trace.csv" -delete
 sh tools/pmc_traffic.sh gpurun_out/pmc_f > gpurun_out/f_pmc.log 2>&1; echo "pmc rc=$? t=$(( $(date +%s) - T0 ))s"
-timeout 300 python tools/bench_tiled.py > gpurun_out/f_tiled.log 2>&1; echo "tiled rc=$? t=$(( $(date +%s) - T0 ))s"; tail -1 gpurun_out/f_tiled.log | cut -c1-400
+for c in c3 c4 c5; do timeout 600 python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/f_$c.log 2>&1; echo "$c rc=$? t=$(( $(date +%s) - T0 ))s"; tail -1 gpurun_out/f_$c.log | cut -c1-300; done

@@ -1,5 +1,6 @@
 #!/bin/bash
-# call D: full -m gpu suite, smoke, default bench (with cpu baseline), rocprofv3 kernel stats of the bench command
+# Quick validation on the GPU box (gpurun -- 'bash tools/gpu_validate_quick.sh'): full -m gpu suite, smoke, default bench
+# (with cpu baseline), rocprofv3 --kernel-trace --stats of the bench command.  About 8 GPU-minutes.
 cd "${GRAFT_REPO_ROOT:-.}"; REPO=$PWD; mkdir -p gpurun_out
 T0=$(date +%s)
 timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider > gpurun_out/d_test_all.log 2>&1
