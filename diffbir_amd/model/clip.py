@@ -160,9 +160,7 @@ class FrozenOpenCLIPEmbedder(NativeModule):
         """The reference keeps CLIP's weights f32 (loop.py:82) and runs it under the pipeline's autocast
         (loop.py:180): nn.Linear / attention in the 16-bit type, LayerNorm and the residual sums in f32.  Same split
         here: GEMM operands in the engine dtype, f32 accumulation, f32 residual stream."""
-        if dtype != getattr(self, "_dtype", None):
-            self._dtype, self._packed = dtype, False
-        return self
+        return super().set_dtype(dtype)
 
     def forward(self, tokens: T) -> T:
         """reference clip.py:37-54: token + positional embedding, 23 of 24 pre-LN blocks with the causal mask, then
