@@ -33,12 +33,17 @@ class ControlLDM:
         # The two networks have the same shapes, and the 16x16 / 8x8 latent levels alone cannot fill 256 CUs.
         self.overlap_streams = True
         self._side_stream = {}
-        # engine option (off by default): capture one network evaluation (ControlNet + UNet, ~700 kernel launches from
-        # Python through ctypes) into a HIP graph per (shape, text context, control scales) and replay it every sampling
-        # step.  Measured on the batch-8 benchmark (profiles/r2_idle_gaps.json): with eager launches the GPU is already
-        # busy 98.2 % of the sampling loop (the host stays ahead; two streams), and replay is not faster (5.69 vs
-        # 5.84 img/s) — it pays only when the host is the bottleneck (small batches, slow hosts).  DBIR_GRAPH=1 enables.
-        self.use_graph = os.environ.get("DBIR_GRAPH", "0") == "1"
+        # engine option: capture one network evaluation (ControlNet + UNet, ~700 kernel launches from Python through
+        # ctypes, ~20 ms of host time) into a HIP graph per (shape, text context, control scales) and replay it every
+        # sampling step.  It pays exactly when the host is the bottleneck: at the benchmark's batch 8 (16 samples per
+        # evaluation, 26 ms of GPU work) eager launches keep the GPU busy 98.2 % of the sampling loop and replay is not
+        # faster (5.69 vs 5.84 img/s, profiles/r2_idle_gaps_*.json); at batch 4 and below the GPU work per evaluation
+        # drops under the host's launch time and the GPU idles.  use_graph: True / False, or None = decide per call:
+        # graphs when the evaluation holds at most `graph_auto_rows` latent pixels (samples x h x w).
+        # DBIR_GRAPH=0 / 1 / auto (default).
+        g = os.environ.get("DBIR_GRAPH", "auto")
+        self.use_graph = None if g == "auto" else g == "1"
+        self.graph_auto_rows = 10 * 64 * 64
         self._graphs: "OrderedDict[tuple, _EvalGraph]" = OrderedDict()
         self._graph_pool = None
         self.max_graphs = 6
@@ -107,7 +112,10 @@ class ControlLDM:
     def forward(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
         """reference cldm.py:160-172. x f32 [B,4,h,w], t [B] (int or fractional), cond {c_txt, c_img} -> f32."""
         from .. import ops
-        if self.use_graph and x_noisy.is_cuda and ops._PROFILE is None and ops._TUNER is None \
+        want = self.use_graph
+        if want is None:
+            want = x_noisy.shape[0] * x_noisy.shape[2] * x_noisy.shape[3] <= self.graph_auto_rows
+        if want and x_noisy.is_cuda and ops._PROFILE is None and ops._TUNER is None \
                 and not torch.cuda.is_current_stream_capturing():
             return self._forward_graphed(x_noisy, t, cond)
         return self._forward_eager(x_noisy, t, cond)
