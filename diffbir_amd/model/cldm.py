@@ -37,13 +37,14 @@ class ControlLDM:
         # ctypes, ~20 ms of host time) into a HIP graph per (shape, text context, control scales) and replay it every
         # sampling step.  It pays exactly when the host is the bottleneck: at the benchmark's batch 8 (16 samples per
         # evaluation, 26 ms of GPU work) eager launches keep the GPU busy 98.2 % of the sampling loop and replay is not
-        # faster (5.69 vs 5.84 img/s, profiles/r2_idle_gaps_*.json); at batch 4 and below the GPU work per evaluation
-        # drops under the host's launch time and the GPU idles.  use_graph: True / False, or None = decide per call:
-        # graphs when the evaluation holds at most `graph_auto_rows` latent pixels (samples x h x w).
+        # faster (5.69 vs 5.84 img/s, profiles/r2_idle_gaps_*.json; call 20: 5.99 eager / 5.82 graph), nor at batch 4
+        # (11.5 eager / 10.6 graph); at batch 1 (2 samples per evaluation) the host's launch time exceeds the GPU work and
+        # replay wins (2.06 -> 2.28 img/s).  use_graph: True / False, or None = decide per call: graphs when the
+        # evaluation holds at most `graph_auto_rows` latent pixels (samples x h x w) = one 512x512 image under CFG.
         # DBIR_GRAPH=0 / 1 / auto (default).
         g = os.environ.get("DBIR_GRAPH", "auto")
         self.use_graph = None if g == "auto" else g == "1"
-        self.graph_auto_rows = 10 * 64 * 64
+        self.graph_auto_rows = 2 * 64 * 64
         self._graphs: "OrderedDict[tuple, _EvalGraph]" = OrderedDict()
         self._graph_pool = None
         self.max_graphs = 6

@@ -106,6 +106,10 @@ def main():
     ap.add_argument("--exclude", default="")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--only", default="", help="incremental: time only these tile ids (and the current table's winner)")
+    ap.add_argument("--size", type=int, default=512, help="image edge: 2048 / 4096 tune the SwinIR / VAE launches of the "
+                    "large-image configs (with --tiled also the 32-sample chunks of the tiled scheduler)")
+    ap.add_argument("--tiled", action="store_true")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     a = ap.parse_args()
     exclude = [int(x) if x.isdigit() else x for x in a.exclude.split(",") if x]
     only = [int(x) for x in a.only.split(",") if x]
@@ -113,16 +117,16 @@ def main():
     os.environ["DBIR_TUNING"] = "0"
     tuning.load()
     dev = torch.device("cuda:0")
-    pipe, cldm, swin = bench.build_engine(dev, torch.float16)
+    pipe, cldm, swin = bench.build_engine(dev, torch.float16 if a.dtype == "fp16" else torch.bfloat16)
     cldm.overlap_streams = False
     cldm.use_graph = False
     import numpy as np
-    lq = torch.as_tensor(np.random.RandomState(0).randint(0, 256, (a.batch, 512, 512, 3)).astype(np.uint8)).to(dev)
-    bench.run_once(pipe, lq, 1)   # warm: packing, caches
+    lq = torch.as_tensor(np.random.RandomState(0).randint(0, 256, (a.batch, a.size, a.size, 3)).astype(np.uint8)).to(dev)
+    bench.run_once(pipe, lq, 1, tiled=a.tiled)   # warm: packing, caches
     torch.cuda.synchronize()
     tuner = Tuner(exclude, only=only, table=table)
     ops._TUNER = tuner
-    bench.run_once(pipe, lq, 1)   # every distinct launch of SwinIR, VAE enc/dec, ControlNet+UNet at batch 2B
+    bench.run_once(pipe, lq, 1, tiled=a.tiled)   # every distinct launch of SwinIR, VAE enc/dec, ControlNet+UNet at batch 2B
     ops._TUNER = None
     torch.cuda.synchronize()
     tiles = {k: dict(tile=r["best"], us=r["us"]) for k, r in tuner.results.items() if r["us"]}
