@@ -304,7 +304,7 @@ def test_cleaner_pipelines_vs_reference_golden(golden_dir, name):
 def test_graph_replay_equals_eager():
     """HIP-graph replay of the network evaluation (automatic for small batches: the host's ~700 launches per evaluation
     outlast the GPU work) runs the same kernels on the same data as eager launching: bit-identical uint8 results,
-    untiled and tiled, and the automatic policy picks graphs for these small evaluations."""
+    untiled and tiled, and the automatic policy picks graphs for the single-image evaluation."""
     dev = _dev()
     pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
     assert cldm.use_graph is None or isinstance(cldm.use_graph, bool)
@@ -317,7 +317,7 @@ def test_graph_replay_equals_eager():
         c = run_pipe(pipe, cases.make_lq(9, 1, 600, 712), 2, "spaced", 5, tiled=True)
         outs[mode] = (a, b, c, len(cldm._graphs))
     assert outs[False][3] == 0 and outs[True][3] >= 2
-    assert outs[None][3] >= 2, "batch 1-2 evaluations must take the graph path under the automatic policy"
+    assert outs[None][3] >= 1, "a single image under CFG (2 samples) must take the graph path under the automatic policy"
     for k in (True, None):
         for i in range(3):
             assert np.array_equal(outs[False][i], outs[k][i]), (k, i)
