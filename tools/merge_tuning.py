@@ -16,7 +16,7 @@ def main():
     dry = "--dry" in sys.argv
     n = 0
     for k, v in sorted(new["tiles"].items()):
-        us = {t: u for t, u in v["us"].items() if u}
+        us = {t: round(u, 1) for t, u in v["us"].items() if u}
         if not us:
             continue
         ent = cur["tiles"].setdefault(k, dict(tile=0, us={}))
