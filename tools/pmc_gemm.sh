@@ -6,8 +6,9 @@ OUT=$REPO/gpurun_out/pmcg
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
-declare -a PROBS=("conv 16 64 64 320 320 14" "conv 16 64 64 320 320 12" "conv 8 128 128 512 512 10" "conv 8 128 128 512 512 13" "lin 65536 320 320 14" "lin 65536 2560 1280 10")
-declare -a SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_WAIT_INST_VMEM SQ_INSTS_VALU_MFMA_MOPS_F16")
+# round 2: the halo-patch convolution (50 de-phased / 52 lockstep), the persistent linear tiles and the small-M floor
+declare -a PROBS=("conv 16 64 64 320 320 50" "conv 16 64 64 320 320 52" "conv 16 32 32 640 640 50" "lin 65536 320 320 71" "lin 65536 320 1280 37" "lin 4096 1280 1280 25")
+declare -a SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum")
 pi=0
 for P in "${PROBS[@]}"; do
   si=0
