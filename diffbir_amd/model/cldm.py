@@ -160,6 +160,30 @@ class ControlLDM:
             for v in (x_noisy, t, c_img):
                 w = v.reshape(G, 2, bs, *v.shape[1:])
                 assert torch.equal(w[:, 0], w[:, 1]), "cfg_pair set on a batch whose halves differ"
+        # the zero convs of the ControlNet run inside the UNet, fused with the skip additions (model/unet.py control_feats;
+        # DBIR_FUSE_CONTROL=0 = A/B: 13 control tensors + 13 separate additions, the reference's op sequence)
+        cn = self.controlnet
+        if os.environ.get("DBIR_FUSE_CONTROL", "1") == "0":
+            return self._forward_eager_unfused(x_noisy, t, c_txt, c_img, pair)
+        if not (self.overlap_streams and x_noisy.is_cuda):
+            feats = cn.features(x_noisy, c_img, t, c_txt, pair=pair)
+            return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, pair=pair,
+                             control_feats=(feats, cn.zero, self.control_scales))
+        main = torch.cuda.current_stream()
+        side = self._side_stream.get(x_noisy.device)
+        if side is None:
+            side = self._side_stream[x_noisy.device] = torch.cuda.Stream(device=x_noisy.device)
+        side.wait_stream(main)                      # inputs produced on the main stream are ready
+        with torch.cuda.stream(side):
+            feats = cn.features(x_noisy, c_img, t, c_txt, pair=pair)
+            done = torch.cuda.Event()
+            done.record(side)
+        for c in feats:                             # allocated on `side`, consumed (and later freed) on `main`
+            c.record_stream(main)
+        return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, control_ready=done, pair=pair,
+                         control_feats=(feats, cn.zero, self.control_scales))
+
+    def _forward_eager_unfused(self, x_noisy: T, t: T, c_txt: T, c_img: T, pair) -> T:
         if not (self.overlap_streams and x_noisy.is_cuda):
             control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales, pair=pair)
             return self.unet(x_noisy, t, c_txt, control, only_mid_control=False, pair=pair)
@@ -167,12 +191,12 @@ class ControlLDM:
         side = self._side_stream.get(x_noisy.device)
         if side is None:
             side = self._side_stream[x_noisy.device] = torch.cuda.Stream(device=x_noisy.device)
-        side.wait_stream(main)                      # inputs produced on the main stream are ready
+        side.wait_stream(main)
         with torch.cuda.stream(side):
             control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales, pair=pair)
             done = torch.cuda.Event()
             done.record(side)
-        for c in control:                           # allocated on `side`, consumed (and later freed) on `main`
+        for c in control:
             c.record_stream(main)
         return self.unet(x_noisy, t, c_txt, control, only_mid_control=False, control_ready=done, pair=pair)
 

@@ -7,7 +7,9 @@ graph is re-expressed for the engine:
   * activations are NHWC 16-bit; every conv / linear is one fused MFMA GEMM launch (bias, time-embedding add,
     residual, GEGLU, control scale in the epilogue);
   * torch.cat of the decoder (controlnet.py:41-43) never happens: the producer of `h` writes into the left part
-    of a concat buffer and `hs.pop() + control.pop()` is written into its right part;
+    of a concat buffer and `hs.pop() + control.pop()` is written into its right part — by the ControlNet's zero-conv
+    GEMM itself when the two networks are evaluated together (`control_feats`: epilogue = (W f + b) * scale + skip,
+    stored into the column slice), so neither the 13 control tensors nor the 13 additions exist as separate passes;
   * to_q/to_k are one GEMM, to_v is emitted transposed for the flash-attention kernel, cross-attention K/V of
     the (constant) text context are computed once per prompt and cached;
   * all per-ResBlock `emb_layers` (SiLU -> Linear, unet.py:166-172,212) are evaluated as ONE GEMM per network
@@ -275,12 +277,16 @@ class ControlledUnetModel(_DiffusionNet):
         self._finish_emb()
 
     def forward(self, x: T, timesteps: T, context: T, control: Optional[List[T]] = None,
-                only_mid_control: bool = False, control_ready=None, pair: Pair = None, **_) -> T:
+                only_mid_control: bool = False, control_ready=None, pair: Pair = None, control_feats=None, **_) -> T:
         """x: f32 NCHW [B,4,h,w]; control: list of 13 NHWC 16-bit tensors (already scaled) or None -> f32 NCHW.
         control_ready: optional torch.cuda.Event recorded by the stream that produces `control` (ControlLDM runs the
         ControlNet concurrently with this encoder); waited for right before the first control tensor is read.
         pair=(G, bs): the caller guarantees the batch is G groups of [bs uncond || bs cond] whose halves have identical
-        x / timesteps (classifier-free guidance) — enables the shared prefix described in the module docstring."""
+        x / timesteps (classifier-free guidance) — enables the shared prefix described in the module docstring.
+        control_feats=(feats, zero_convs, scales): instead of `control`, the ControlNet's 13 pre-zero-conv feature maps
+        (`ControlNet.features`), its packed zero convs and the control scales: `skip + zero_conv(f) * scale` is then ONE
+        GEMM per skip connection, written straight into the concat buffer (same arithmetic: the control tensor is
+        rounded to 16 bit before the add in both forms)."""
         self._ensure_packed()
         ctx_kv = self.context_kv(context)
         emb_all = self._time_emb(timesteps)
@@ -291,7 +297,21 @@ class ControlledUnetModel(_DiffusionNet):
         if control_ready is not None:
             torch.cuda.current_stream().wait_event(control_ready)
         control = list(control) if control is not None else None
+        if control_feats is not None:
+            assert control is None
+            cf = [(f, z, float(sc)) for f, z, sc in zip(*control_feats)]
         B = h.shape[0]
+
+        def add_control(skip: T, out: T) -> bool:
+            """out = skip + control (popping the next control / feature); False when there is no control."""
+            if control_feats is not None:
+                f, z, sc = cf.pop()
+                ops.linear(f, z, out_scale=sc, residual=skip, out=out)
+                return True
+            if control is not None:
+                ops.add_scaled(skip, control.pop(), 1.0, out=out)
+                return True
+            return False
 
         def cat_buf(blk, hh, ww):
             return torch.empty((B, hh, ww, blk["cin"]), dtype=self._dtype, device=h.device)
@@ -300,16 +320,12 @@ class ControlledUnetModel(_DiffusionNet):
         b0 = self.plan.output[0]
         buf = cat_buf(b0, h.shape[1], h.shape[2])
         left = buf[..., : b0["cin"] - b0["skip"]]
-        if control is not None:
-            ops.add_scaled(h, control.pop(), 1.0, out=left)
-        else:
+        if not add_control(h, left):
             left.copy_(h)
         for i, (res, att, up, b) in enumerate(self.dec):
             skip = hs.pop()
             right = buf[..., b["cin"] - b["skip"]:]
-            if control is not None and not only_mid_control:
-                ops.add_scaled(skip, control.pop(), 1.0, out=right)
-            else:
+            if only_mid_control or not add_control(skip, right):
                 right.copy_(skip)
             last = i == len(self.dec) - 1
             nxt = None if last else self.plan.output[i + 1]
@@ -347,6 +363,13 @@ class ControlNet(_DiffusionNet):
                 pair: Pair = None, **_) -> List[T]:
         """-> 13 control tensors (NHWC 16-bit), multiplied by `scales` (cldm.py:164) in the zero-conv epilogue.
         pair: as in ControlledUnetModel.forward (x, hint and timesteps identical in both halves of every group)."""
+        feats = self.features(x, hint, timesteps, context, pair=pair)
+        scales = scales if scales is not None else [1.0] * len(feats)
+        return [ops.linear(f, z, out_scale=float(s)) for f, z, s in zip(feats, self.zero, scales)]
+
+    def features(self, x: T, hint: T, timesteps: T, context: T, pair: Pair = None) -> List[T]:
+        """The 13 feature maps the zero convs are applied to (12 encoder outputs + middle block), NHWC 16-bit.  ControlLDM
+        hands them to ControlledUnetModel.forward(control_feats=...) so the zero convs run fused with the skip additions."""
         self._ensure_packed()
         ctx_kv = self.context_kv(context)
         emb_all = self._time_emb(timesteps)
@@ -356,8 +379,6 @@ class ControlNet(_DiffusionNet):
             x, hint = _unique_of_pairs(x, pair), _unique_of_pairs(hint, pair)
         h = ops.nchw_to_nhwc(x, hint, 8, self._dtype)
         hs, mid = self._encode(h, emb_all, ctx_kv, pair)
-        feats = hs + [mid]
-        scales = scales if scales is not None else [1.0] * len(feats)
-        return [ops.linear(f, z, out_scale=float(s)) for f, z, s in zip(feats, self.zero, scales)]
+        return hs + [mid]
 
     __call__ = forward
