@@ -242,3 +242,23 @@ def test_cleaner_pipelines_vs_reference_golden(monkeypatch, golden_dir, name):
     ref = np.load(os.path.join(golden_dir, "cleaners.npz"))["pipe_" + name]
     assert out.shape == ref.shape and out.dtype == np.uint8
     assert cases.psnr_u8(out, ref) > 60.0
+
+
+@torch.no_grad()
+def test_fused_control_injection_equals_two_pass_form(engine, monkeypatch):
+    """`skip + zero_conv(f) * scale` evaluated as one GEMM per skip connection inside the UNet (model/unet.py
+    control_feats) equals the reference's op sequence (13 control tensors from ControlNet.forward, then 13 additions)."""
+    pipe, cldm, swin = engine
+    rs = cases.NoiseStream(13)
+    x, c_img = rs((2, 4, 16, 16)), rs((2, 4, 16, 16)) * 0.5
+    c_txt = rs((2, 77, cldm.unet.cfg["context_dim"]))
+    t = torch.tensor([801.0, 17.5])
+    cldm.control_scales = [0.5 + 0.05 * i for i in range(13)]
+    fused = cldm(x, t, dict(c_txt=c_txt, c_img=c_img))
+    monkeypatch.setenv("DBIR_FUSE_CONTROL", "0")
+    two_pass = cldm(x, t, dict(c_txt=c_txt, c_img=c_img))
+    assert rel_err(fused, two_pass.numpy())[0] < 1e-6
+    # the reference-facing ControlNet API still returns the 13 scaled control tensors
+    ctrl = cldm.controlnet(x, c_img, t, c_txt, scales=cldm.control_scales)
+    feats = cldm.controlnet.features(x, c_img, t, c_txt)
+    assert len(ctrl) == len(feats) == 13 and all(c.shape == f.shape for c, f in zip(ctrl, feats))
