@@ -34,7 +34,7 @@ def load(path):
 
 
 def short(name):
-    n = name.split("(")[0]
+    n = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
     n = n.replace("void (anonymous namespace)::", "").replace("void ", "")
     return n[:70]
 
