@@ -105,9 +105,11 @@ def main(argv=None):
     args = parse_args(argv)
     args.device = check_device(args.device)
     set_seed(args.seed)
-    from diffbir.inference import BFRInferenceLoop, BIDInferenceLoop, BSRInferenceLoop
+    from diffbir.inference import BFRInferenceLoop, BIDInferenceLoop, BSRInferenceLoop, CustomInferenceLoop
     if args.version == "custom":
-        raise SystemExit("--version custom (self-trained models through the training config) is outside this engine")
+        CustomInferenceLoop(args).run()
+        print("done!")
+        return
     loops = {"sr": BSRInferenceLoop, "face": BFRInferenceLoop, "denoise": BIDInferenceLoop}
     if args.task not in loops:
         raise SystemExit(f"--task {args.task}: the RetinaFace detection / alignment front-end is outside this engine's "
