@@ -122,3 +122,93 @@ def wavelet_reconstruction(content_feat: T, style_feat: T, levels: int = 5) -> T
     c = content_feat.float().contiguous()
     s = style_feat.float().contiguous()
     return ops.colorfix(c, low(c), low(s))
+
+
+# ---- the remaining helpers of reference utils/common.py that user code imports (metrics, wavelet pieces, monitors) ------
+def wavelet_blur(image: T, radius: int) -> T:
+    """reference utils/common.py:29-48: depthwise [1,2,1]x[1,2,1]/16 blur with dilation `radius`, replicate padding —
+    the engine's `dbir_wavelet_blur` kernel (f32 NCHW in / out)."""
+    return ops.wavelet_blur(image.float().contiguous(), radius)
+
+
+def wavelet_decomposition(image: T, levels: int = 5) -> Tuple[T, T]:
+    """reference utils/common.py:51-63 -> (high frequencies, low frequencies); the reference's running sum of
+    (img_i - low_i) telescopes to image - low_last."""
+    img = image.float().contiguous()
+    low = img
+    for i in range(levels):
+        low = ops.wavelet_blur(low, 2 ** i)
+    return img - low, low
+
+
+def to(obj: Any, device) -> Any:
+    """reference utils/common.py:300-310: move every tensor of a nested dict / tuple / list to `device`."""
+    if torch.is_tensor(obj):
+        return obj.to(device)
+    if isinstance(obj, dict):
+        return {k: to(v, device) for k, v in obj.items()}
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(to(v, device) for v in obj)
+    return obj
+
+
+_BT601 = ((65.481, -37.797, 112.0), (128.553, -74.203, -93.786), (24.966, 112.0, -18.214))
+
+
+def rgb2ycbcr_pt(img: T, y_only: bool = False) -> T:
+    """reference utils/common.py:314-346 (ITU-R BT.601, studio swing): RGB [n,3,h,w] in [0,1] -> Y or YCbCr in [0,1].
+    Metric code, not on the restoration path: plain torch."""
+    m = torch.tensor(_BT601, dtype=img.dtype, device=img.device)
+    off = torch.tensor((16.0, 128.0, 128.0), dtype=img.dtype, device=img.device)
+    if y_only:
+        m, off = m[:, :1], off[:1]
+    out = torch.einsum("nchw,ck->nkhw", img, m) + off.view(1, -1, 1, 1)
+    return out / 255.0
+
+
+def calculate_psnr_pt(img: T, img2: T, crop_border: int, test_y_channel: bool = False) -> T:
+    """reference utils/common.py:350-390: per-image PSNR of [0,1] images (optionally on the Y channel, borders cropped),
+    the metric BASELINE.json's parity tolerance is stated in."""
+    assert img.shape == img2.shape, f"Image shapes are different: {img.shape}, {img2.shape}."
+    if crop_border != 0:
+        img = img[:, :, crop_border:-crop_border, crop_border:-crop_border]
+        img2 = img2[:, :, crop_border:-crop_border, crop_border:-crop_border]
+    if test_y_channel:
+        img, img2 = rgb2ycbcr_pt(img, y_only=True), rgb2ycbcr_pt(img2, y_only=True)
+    mse = ((img.double() - img2.double()) ** 2).mean(dim=[1, 2, 3])
+    return 10.0 * torch.log10(1.0 / (mse + 1e-8))
+
+
+TRACE_VRAM = int(os.environ.get("TRACE_VRAM", False))
+
+
+class VRAMPeakMonitor:
+    """reference utils/common.py:260-279: context manager printing the HBM peak before / after a block when TRACE_VRAM=1."""
+
+    def __init__(self, tag: str) -> None:
+        self.tag = tag
+
+    def __enter__(self):
+        self.peak_before = torch.cuda.max_memory_allocated() / 1024 ** 3 if torch.cuda.is_available() else 0.0
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            peak_after = torch.cuda.max_memory_allocated() / 1024 ** 3
+            if TRACE_VRAM:
+                print(f"\033[93mVRAM peak before {self.tag}: {self.peak_before:.2f} GB, after: {peak_after:.2f} GB\033[0m")
+        return False
+
+
+def trace_vram_usage(tag: str) -> Callable:
+    """reference utils/common.py:236-257: decorator form of VRAMPeakMonitor (identity unless TRACE_VRAM=1)."""
+    def deco(func: Callable) -> Callable:
+        if not TRACE_VRAM:
+            return func
+
+        def wrapped(*args, **kwargs):
+            with VRAMPeakMonitor(tag):
+                return func(*args, **kwargs)
+        return wrapped
+    return deco

@@ -369,3 +369,38 @@ def test_custom_inference_loop_end_to_end(tmp_path, monkeypatch):
                             a.start_point_type, a.sampler, a.noise_aug, a.rescale_cfg, a.s_churn, a.s_tmin, a.s_tmax,
                             a.s_noise, a.eta, a.order)
     assert np.array_equal(out, ref[0])
+
+
+@needs_ref
+def test_utils_common_helpers_match_reference(monkeypatch):
+    """The metric / wavelet / misc helpers of reference utils/common.py that user code imports."""
+    from oracle.ref_import import load_reference
+    load_reference()
+    import importlib
+    ref = importlib.import_module("diffbir.utils.common")
+    from diffbir_amd.utils import common as mine
+    from tests import emu_ops
+    emu_ops.install(monkeypatch)
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand(2, 3, 40, 56, generator=g), torch.rand(2, 3, 40, 56, generator=g)
+    for y in (False, True):
+        assert torch.allclose(mine.rgb2ycbcr_pt(a, y_only=y), ref.rgb2ycbcr_pt(a, y_only=y), atol=1e-6)
+        for crop in (0, 4):
+            assert torch.allclose(mine.calculate_psnr_pt(a, b, crop, test_y_channel=y),
+                                  ref.calculate_psnr_pt(a, b, crop, test_y_channel=y), atol=1e-9)
+    assert torch.allclose(mine.wavelet_blur(a, 4), ref.wavelet_blur(a, 4), atol=1e-6)
+    hi, lo = mine.wavelet_decomposition(a)
+    rhi, rlo = ref.wavelet_decomposition(a)
+    assert torch.allclose(hi, rhi, atol=1e-5) and torch.allclose(lo, rlo, atol=1e-6)
+    assert torch.allclose(mine.wavelet_reconstruction(a, b), ref.wavelet_reconstruction(a, b), atol=1e-5)
+    nested = {"x": a, "l": [b, (a, 3)], "s": "keep"}
+    moved = mine.to(nested, "cpu")
+    assert moved["s"] == "keep" and isinstance(moved["l"][1], tuple) and moved["l"][1][1] == 3 and torch.equal(moved["x"], a)
+    with mine.VRAMPeakMonitor("block"):
+        pass
+    assert mine.trace_vram_usage("f")(len) is len or mine.TRACE_VRAM
+    missing = [n for n in ("instantiate_from_config", "load_model_from_url", "load_file_from_url", "sliding_windows",
+                           "gaussian_weights", "make_tiled_fn", "wavelet_blur", "wavelet_decomposition",
+                           "wavelet_reconstruction", "calculate_psnr_pt", "rgb2ycbcr_pt", "to", "VRAMPeakMonitor",
+                           "trace_vram_usage", "get_obj_from_str") if not hasattr(mine, n)]
+    assert not missing, missing
