@@ -372,6 +372,38 @@ __global__ void gn_finalize(const u16* __restrict__ x, long long ldx, const floa
 }
 }  // namespace
 
+namespace {
+// partial sums of gn_stats -> per (sample, channel) affine of the normalisation: ab[b][0][c] = rstd_g * gamma[c],
+// ab[b][1][c] = beta[c] - mean_g * rstd_g * gamma[c]  (y = x * a + s; consumed by the fused transformer head, xformer.hip)
+template <typename T>
+__global__ void gn_finalize_affine(const u16* __restrict__ x, long long ldx, const float* __restrict__ partial,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ ab, int nchunk, int HW, int C, int groups, float eps) {
+  __shared__ float stat[128];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int cpg = C / groups;
+  if (t < groups) {
+    const float* pb = partial + (long long)b * nchunk * 2 * groups;
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      a += pb[(long long)k * 2 * groups + t];
+      q += pb[(long long)k * 2 * groups + groups + t];
+    }
+    const float n = (float)HW * (float)cpg;
+    const float ms = a / n;
+    stat[t] = ms + T::to_f32(x[(long long)b * HW * ldx + t * cpg]);
+    stat[groups + t] = rsqrtf(fmaxf(q / n - ms * ms, 0.f) + eps);
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float a = stat[groups + g] * gamma[c];
+    ab[(long long)b * 2 * C + c] = a;
+    ab[(long long)b * 2 * C + C + c] = beta[c] - stat[g] * a;
+  }
+}
+}  // namespace
+
 extern "C" int dbir_groupnorm_nchunk(int HW, int C) {
   (void)C;
   int n = (HW + 15) / 16;
@@ -462,6 +494,35 @@ extern "C" int dbir_groupnorm_stats(int dtype, const void* x, long long ldx, int
     return DBIR_ERR_ARG;
   }
   DBIR_CHECK_LAUNCH("dbir_groupnorm_stats");
+  return DBIR_OK;
+}
+
+extern "C" int dbir_groupnorm_affine(int dtype, const void* x, long long ldx, int B, int HW, int C, int groups, float eps,
+                                     const float* gamma, const float* beta, float* workspace, float* scale_shift,
+                                     void* stream) {
+  DBIR_CHECK_ARG(x && workspace && scale_shift && gamma && beta, "dbir_groupnorm_affine: null pointer");
+  DBIR_CHECK_ARG(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && C <= 4096 && groups <= 64 && B > 0 && B <= 65535,
+                 "dbir_groupnorm_affine: need C%%8==0, C%%groups==0, ld%%8==0, groups<=64 (C=%d)", C);
+  int nchunk, rows_per_chunk, rpi, threads;
+  DBIR_CHECK_ARG(gn_geometry(B, HW, C, groups, nchunk, rows_per_chunk, rpi, threads),
+                 "dbir_groupnorm_affine: unsupported C / groups combination");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t sh1 = (size_t)rpi * 2 * C * sizeof(float);
+  if (dtype == DBIR_F16) {
+    hipLaunchKernelGGL((gn_stats<F16>), dim3(nchunk, B), dim3(threads), sh1, s, (const u16*)x, ldx, workspace, HW, C,
+                       groups, rows_per_chunk, rpi);
+    hipLaunchKernelGGL((gn_finalize_affine<F16>), dim3(B), dim3(256), 0, s, (const u16*)x, ldx, workspace, gamma, beta,
+                       scale_shift, nchunk, HW, C, groups, eps);
+  } else if (dtype == DBIR_BF16) {
+    hipLaunchKernelGGL((gn_stats<BF16>), dim3(nchunk, B), dim3(threads), sh1, s, (const u16*)x, ldx, workspace, HW, C,
+                       groups, rows_per_chunk, rpi);
+    hipLaunchKernelGGL((gn_finalize_affine<BF16>), dim3(B), dim3(256), 0, s, (const u16*)x, ldx, workspace, gamma, beta,
+                       scale_shift, nchunk, HW, C, groups, eps);
+  } else {
+    dbir_set_error("dbir_groupnorm_affine: bad dtype");
+    return DBIR_ERR_ARG;
+  }
+  DBIR_CHECK_LAUNCH("dbir_groupnorm_affine");
   return DBIR_OK;
 }
 

@@ -34,6 +34,9 @@ T = torch.Tensor
 Pair = Optional[Tuple[int, int]]
 # evaluate the part of the encoder that cannot depend on the text context once per distinct sample of a CFG batch
 SHARE_CFG_PREFIX = os.environ.get("DBIR_SHARE_CFG_PREFIX", "1") != "0"
+# run the transformer blocks of the 64x64 level (C = 320) on the fused row-panel kernels (csrc/xformer.hip):
+# groupnorm_affine -> xf_head -> self-attention -> xf_tail instead of 16 launches (A/B switch: DBIR_FUSED_XF=0)
+FUSED_XF = os.environ.get("DBIR_FUSED_XF", "1") != "0"
 
 
 def _unique_of_pairs(t: T, pair: Tuple[int, int]) -> T:
@@ -56,7 +59,7 @@ class _Res:
 
 class _Attn:
     __slots__ = ("gn", "proj_in", "ln1", "qk1", "v1", "out1", "ln2", "q2", "k2", "v2", "out2", "ln3", "ff1", "ff2",
-                 "proj_out", "ch", "heads", "ctx_idx")
+                 "proj_out", "ch", "heads", "ctx_idx", "xf")
 
 
 class _DiffusionNet(NativeModule):
@@ -111,6 +114,18 @@ class _DiffusionNet(NativeModule):
         a.ff1 = ops.pack_geglu(self._w(f"{q}.ff.net.0.proj.weight"), self._w(f"{q}.ff.net.0.proj.bias"), self._dtype,
                                self._device)
         a.ff2 = self._pk_lin(f"{q}.ff.net.2")
+        a.xf = None
+        if ch == 320 and FUSED_XF:  # fused row-panel kernels (the per-launch weights above stay for other sequence lengths)
+            names = {"proj_in": f"{p}.proj_in", "norm1": f"{q}.norm1", "q1": f"{q}.attn1.to_q", "k1": f"{q}.attn1.to_k",
+                     "v1": f"{q}.attn1.to_v", "out1": f"{q}.attn1.to_out.0", "norm2": f"{q}.norm2", "q2": f"{q}.attn2.to_q",
+                     "out2": f"{q}.attn2.to_out.0", "norm3": f"{q}.norm3", "ff1": f"{q}.ff.net.0.proj", "ff2": f"{q}.ff.net.2",
+                     "proj_out": f"{p}.proj_out"}
+            w = {}
+            for short, key in names.items():
+                w[short + ".w"] = self._w(key + ".weight")
+                if key + ".bias" in self._sd:
+                    w[short + ".b"] = self._w(key + ".bias")
+            a.xf = ops.pack_xf_block(w, self._dtype, self._device)
         a.ctx_idx = len(self._attn_layers)
         self._attn_layers.append(a)
         return a
@@ -173,7 +188,10 @@ class _DiffusionNet(NativeModule):
             k = ops.linear(c, a.k2).reshape(B, L, a.ch)
             vt = torch.zeros((B, a.ch, Lp), dtype=self._dtype, device=c.device)
             ops.linear_t(c, a.v2, L, vt)
-            kv.append((k, vt))
+            if a.xf is not None and L <= 96:  # fragment-ordered copy for the fused tail kernel
+                kv.append((k, vt) + tuple(ops.pack_context_frags(k, vt, L, a.heads)))
+            else:
+                kv.append((k, vt))
         if len(self._ctx_cache) > 64:
             self._ctx_cache.clear()
         self._ctx_cache[key] = kv
@@ -186,6 +204,14 @@ class _DiffusionNet(NativeModule):
         B, H, W, C = x.shape
         L = H * W
         scale = self.plan.head_dim ** -0.5
+        ckv = ctx_kv[a.ctx_idx]
+        if a.xf is not None and len(ckv) == 4 and ops.xf_supported(C, L, ckv[0].shape[1]):
+            ab = ops.groupnorm_affine(x, a.gn[0], a.gn[1], 1e-6)
+            h, qk, vt = ops.xf_head(x, ab, a.xf, L)
+            o = torch.empty((B, L, C), dtype=x.dtype, device=x.device)
+            ops.attention(qk[..., :C], qk[..., C:], vt, o, a.heads, L, scale)
+            return ops.xf_tail(o, h, x, a.xf, ckv[2], ckv[3], ckv[0].shape[1], scale, L, out=out,
+                               pair_bs=pair[1] if pair is not None else 0)
         hn = ops.groupnorm(x, a.gn[0], a.gn[1], 1e-6, False)
         h = ops.linear(hn.reshape(B * L, C), a.proj_in)
         # self attention
@@ -204,7 +230,7 @@ class _DiffusionNet(NativeModule):
         # cross attention (K/V precomputed)
         n = ops.layernorm(h, a.ln2[0], a.ln2[1])
         q = ops.linear(n, a.q2).reshape(B, L, C)
-        k_ctx, vt_ctx = ctx_kv[a.ctx_idx]
+        k_ctx, vt_ctx = ckv[0], ckv[1]
         ops.attention(q, k_ctx, vt_ctx, o, a.heads, k_ctx.shape[1], scale)
         h = ops.linear(o.reshape(B * L, C), a.out2, residual=h)
         # GEGLU feed-forward

@@ -47,7 +47,11 @@ SIGNATURES = {
     "dbir_groupnorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P],
     "dbir_groupnorm_stats": [_I, _P, _LL, _I, _I, _I, _I, _P, _P, _P],
     "dbir_groupnorm_apply": [_I, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "dbir_groupnorm_affine": [_I, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "dbir_layernorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _F, _P],
+    "dbir_xf_tile_bytes": [], "dbir_xf_head_tiles": [], "dbir_xf_tail_tiles": [],
+    "dbir_xf_head": [_I, _P, _LL, _P, _P, _LL, _P, _LL, _P, _LL, _LL, _I, _I, _I, _P, _LL, _P, _P],
+    "dbir_xf_tail": [_I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _LL, _P, _P, _P, _I, _F, _I, _P],
     "dbir_softmax_rows": [_I, _P, _LL, _LL, _I, _P],
     "dbir_clip_embed": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dbir_add_layernorm_f32": [_I, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _P],

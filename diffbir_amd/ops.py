@@ -349,6 +349,33 @@ def window_attention(qkv: T, out: T, bias_table: T, C: int, heads: int, ws: int,
     return out
 
 
+# ------------------------------------------------------------------------------------------------ fused transformer block
+# (csrc/xformer.hip, host side in diffbir_amd/xformer.py).  Counted in the GEMM family for the roofline: the FLOPs are
+# those of the linears the kernels replace (bench.py), the LayerNorms / text cross-attention inside are not credited.
+from . import xformer as _xf  # noqa: E402
+
+XfBlock = _xf.XfBlock
+pack_xf_block = _xf.pack_block
+pack_context_frags = _xf.pack_context_frags
+xf_supported = _xf.supported
+groupnorm_affine = _xf.groupnorm_affine
+
+
+def xf_head(x: T, ab: T, blk: "XfBlock", L: int):
+    """GroupNorm-apply -> proj_in -> h; LayerNorm1 -> q | k, v^T (attention.py:344-345, 266, 189-200)."""
+    M, C = _rows(x), x.shape[-1]
+    with _Timed("gemm", 2.0 * M * C * 4 * C, f"xf_head M{M} C{C}", 2.0 * M * C * 5 + 2.0 * 4 * C * C):
+        return _xf.xf_head(x, ab, blk, L)
+
+
+def xf_tail(attn: T, h: T, x: T, blk: "XfBlock", kf: T, vf: T, Lk: int, scale: float, L: int, out: Optional[T] = None,
+            pair_bs: int = 0, stop_after: int = 0) -> T:
+    """Everything of the transformer block after the self-attention (attention.py:201-216, 266-273, 19-45, 350-353)."""
+    M, C = _rows(attn) * (2 if pair_bs else 1), attn.shape[-1]
+    with _Timed("gemm", 2.0 * M * C * 16 * C, f"xf_tail M{M} C{C}", 2.0 * M * C * 4 + 2.0 * 16 * C * C):
+        return _xf.xf_tail(attn, h, x, blk, kf, vf, Lk, scale, L, out=out, pair_bs=pair_bs, stop_after=stop_after)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 def groupnorm(x: T, gamma: T, beta: T, eps: float, silu: bool, out: Optional[T] = None, groups: int = 32) -> T:
     """x: [B, H, W, C] (or [B, HW, C]) 16-bit; gamma/beta f32 [C]."""

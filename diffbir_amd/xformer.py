@@ -1,0 +1,219 @@
+"""Host side of the fused transformer-block kernels (csrc/xformer.hip): weight-stream packing and the op wrappers.
+
+A SpatialTransformer of the 64x64 latent level (C = 320; reference attention.py:334-353 around
+BasicTransformerBlock._forward, attention.py:265-274) runs as
+
+    groupnorm_affine -> xf_head -> attention (self) -> xf_tail
+
+The kernels keep a 128-row activation panel in LDS and stream ALL weights of the block through a 3-slot LDS ring as
+one flat sequence of tiles; this module lays that sequence out.  A tile is 20 "fragment pieces" of 1 KB — piece
+(block j, k-step s) holds rows [32 j, 32 j + 32) x columns [16 s, 16 s + 16) of a weight matrix [N, K] in the order an
+MFMA 32x32x16 operand fragment is read: lane = 32 * hi + lq owns row 32 j + lq, columns 16 s + 8 hi .. + 8 — followed by
+512 B of f32 side data (the GEGLU projection bias of a feed-forward chunk).  Tile order = consumption order:
+
+  head: proj_in, to_q, to_k, to_v                      10 tiles each: K tile kt = pieces [k-step 2 kt + ksl][block j]
+  tail: attn1.to_out, attn2.to_q, attn2.to_out         10 tiles each, as above
+        20 feed-forward chunks of 64 hidden units c:   4 tiles of ff.net.0.proj rows (value, gate blocks interleaved per
+                                                       32: blocks 4c .. 4c+3), tile i = pieces [k-step 5 i + ksl][block];
+                                                       2 tiles of ff.net.2 columns [64 c, 64 c + 64): [k-step 2 i + ksl][j]
+        proj_out                                       10 tiles
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import native
+
+T = torch.Tensor
+XC = 320
+TILE_W, TILE_AUX = 20480, 512
+TILE_BYTES = TILE_W + TILE_AUX
+HEAD_TILES, TAIL_TILES = 40, 160
+LK_PAD = 96
+
+
+@dataclass
+class XfBlock:
+    """Packed weights of one transformer block for xf_head / xf_tail."""
+    head_stream: T          # uint8 [HEAD_TILES, TILE_BYTES]
+    head_prm: T             # f32 [3, C]: proj_in bias, norm1 gamma, norm1 beta
+    tail_stream: T          # uint8 [TAIL_TILES, TILE_BYTES]
+    tail_prm: T             # f32 [8, C]
+    heads: int
+    logical: Dict[str, T]   # the unpacked 16-bit weights / f32 vectors (validation tools and the CPU test double)
+
+
+def _pieces(w: T) -> T:
+    """[N, K] (N % 32 == 0, K % 16 == 0) -> [N/32, K/16, 64, 8]: fragment pieces (see module docstring)."""
+    N, K = w.shape
+    return w.reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(N // 32, K // 16, 64, 8).contiguous()
+
+
+def _tiles_n320(w: T) -> T:
+    """[320, K] -> [K/32 tiles, 20 pieces, 64, 8], piece index = ksl * 10 + j."""
+    p = _pieces(w)                                   # [10, K/16, 64, 8]
+    nkt = p.shape[1] // 2
+    return p.reshape(10, nkt, 2, 64, 8).permute(1, 2, 0, 3, 4).reshape(nkt, 20, 64, 8)
+
+
+def _geglu_interleave(w: T, b: T) -> Tuple[T, T]:
+    """ff.net.0.proj [2*nh, K] (values | gates, attention.py:24-26) -> rows in blocks of 32: value block i, gate block i."""
+    nh = w.shape[0] // 2
+    wi = torch.stack([w[:nh].reshape(nh // 32, 32, -1), w[nh:].reshape(nh // 32, 32, -1)], dim=1).reshape(2 * nh, -1)
+    bi = torch.stack([b[:nh].reshape(nh // 32, 32), b[nh:].reshape(nh // 32, 32)], dim=1).reshape(2 * nh)
+    return wi, bi
+
+
+def _finish_stream(tiles: T, aux: Optional[T], device) -> T:
+    """tiles 16-bit [T, 20, 64, 8] (+ aux f32 [T, 128] or None) -> uint8 [T, TILE_BYTES] on `device`."""
+    nt = tiles.shape[0]
+    out = torch.zeros((nt, TILE_BYTES), dtype=torch.uint8)
+    out[:, :TILE_W] = tiles.contiguous().view(torch.uint8).reshape(nt, TILE_W)
+    if aux is not None:
+        out[:, TILE_W:] = aux.contiguous().view(torch.uint8).reshape(nt, TILE_AUX)
+    return out.to(device)
+
+
+def pack_block(w: Dict[str, T], dtype, device) -> XfBlock:
+    """w: the block's tensors by short name (any float dtype / device) —
+    proj_in.{w,b}, norm1.{w,b}, q1.w, k1.w, v1.w, out1.{w,b}, norm2.{w,b}, q2.w, out2.{w,b}, norm3.{w,b}, ff1.{w,b},
+    ff2.{w,b}, proj_out.{w,b}."""
+    g = {k: v.detach().float().cpu().reshape(v.shape[0], -1) if v.dim() > 1 else v.detach().float().cpu() for k, v in w.items()}
+    C = g["proj_in.w"].shape[0]
+    assert C == XC and g["ff2.w"].shape == (C, 4 * C), "fused transformer kernels are built for C = 320"
+    head_prm = torch.stack([g["proj_in.b"], g["norm1.w"], g["norm1.b"]]).contiguous().to(device)
+    tail_prm = torch.stack([g["out1.b"], g["norm2.w"], g["norm2.b"], g["out2.b"], g["norm3.w"], g["norm3.b"],
+                            g["ff2.b"], g["proj_out.b"]]).contiguous().to(device)
+    logical = {k: (v.to(dtype) if k.endswith(".w") and not k.startswith("norm") else v).to(device) for k, v in g.items()}
+    if torch.empty(0, dtype=dtype).element_size() != 2:  # f32 test double (CPU wiring tests): no kernel streams
+        e = torch.empty((0, TILE_BYTES), dtype=torch.uint8, device=device)
+        return XfBlock(e, head_prm, e, tail_prm, C // 64, logical)
+    h = lambda name: g[name].to(dtype)  # noqa: E731  (weights are rounded to the 16-bit compute type once, here)
+    head = torch.cat([_tiles_n320(h(n)) for n in ("proj_in.w", "q1.w", "k1.w", "v1.w")])
+    w1, b1 = _geglu_interleave(g["ff1.w"], g["ff1.b"])
+    p1 = _pieces(w1.to(dtype))                      # [80 blocks, 20 k-steps, 64, 8]
+    p2 = _pieces(h("ff2.w"))                        # [10 blocks, 80 k-steps, 64, 8]
+    ff_tiles, ff_aux = [], []
+    for c in range(4 * C // 64):
+        for i in range(4):                          # piece = ksl * 4 + block
+            ff_tiles.append(p1[4 * c:4 * c + 4, 5 * i:5 * i + 5].permute(1, 0, 2, 3).reshape(20, 64, 8))
+            ff_aux.append(b1[128 * c:128 * c + 128])
+        for i in range(2):                          # piece = ksl * 10 + j
+            ff_tiles.append(p2[:, 4 * c + 2 * i:4 * c + 2 * i + 2].permute(1, 0, 2, 3).reshape(20, 64, 8))
+            ff_aux.append(torch.zeros(128))
+    tail = torch.cat([_tiles_n320(h("out1.w")), _tiles_n320(h("q2.w")), _tiles_n320(h("out2.w")),
+                      torch.stack(ff_tiles), _tiles_n320(h("proj_out.w"))])
+    tail_aux = torch.cat([torch.zeros(30, 128), torch.stack(ff_aux), torch.zeros(10, 128)])
+    assert head.shape[0] == HEAD_TILES and tail.shape[0] == TAIL_TILES
+    return XfBlock(_finish_stream(head, None, device), head_prm, _finish_stream(tail, tail_aux, device), tail_prm,
+                   C // 64, logical)
+
+
+def pack_context_frags(k: T, vt: T, Lk: int, heads: int) -> Tuple[T, T]:
+    """Text-context K [B, Lk, C] and V^T [B, C, >= Lk] of one block -> MFMA fragment order per (sample, head):
+    kf [B, heads, 3, 4, 64, 8]: lane 32 hi + lq of (key block kb, d-step ks) = K[32 kb + lq, 64 h + 16 ks + 8 hi ..+8]
+    vf [B, heads, 2, 6, 64, 8]: lane 32 hi + lq of (d block t, key-step s)  = V^T[64 h + 32 t + lq, keys 16 s + 4 hi +
+    {0..3}, 16 s + 8 + 4 hi + {0..3}] — the key order in which the softmax probabilities sit in the S^T accumulators.
+    Keys >= Lk are zero."""
+    B, _, C = k.shape
+    assert Lk <= LK_PAD and C == heads * 64
+    kp = torch.zeros((B, LK_PAD, C), dtype=k.dtype, device=k.device)
+    kp[:, :Lk] = k[:, :Lk]
+    kf = kp.reshape(B, 3, 32, heads, 4, 2, 8).permute(0, 3, 1, 4, 5, 2, 6).reshape(B, heads, 3, 4, 64, 8).contiguous()
+    vp = torch.zeros((B, C, LK_PAD), dtype=vt.dtype, device=vt.device)
+    vp[:, :, :Lk] = vt[:, :, :Lk]
+    # key(s, hi, p) = 16 s + 8 (p >> 2) + 4 hi + (p & 3): split keys as [s 6][half 2][hi 2][e 4] -> order [s][hi][half][e]
+    vv = vp.reshape(B, heads, 2, 32, 6, 2, 2, 4)                    # [B, h, t, lq, s, half, hi, e]
+    vf = vv.permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(B, heads, 2, 6, 64, 8).contiguous()
+    return kf, vf
+
+
+# ------------------------------------------------------------------------------------------------ op wrappers
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: T) -> int:
+    if t.dtype == torch.float16:
+        return native.F16
+    if t.dtype == torch.bfloat16:
+        return native.BF16
+    raise TypeError(f"expected a 16-bit tensor, got {t.dtype}")
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise native.NativeError("diffbir_amd ops need GPU tensors (no CPU fallback in the product path)")
+
+
+def _rows_ld(t: T) -> Tuple[int, int]:
+    """(rows, row stride) of a channels-last activation whose leading dims are dense over the row stride."""
+    assert t.stride(-1) == 1
+    ld = t.stride(-2)
+    exp = ld
+    for d in range(t.dim() - 2, 0, -1):
+        exp *= t.shape[d]
+        assert t.stride(d - 1) == exp or t.shape[d - 1] == 1, f"leading dims not dense: {t.shape} {t.stride()}"
+    n = 1
+    for s in t.shape[:-1]:
+        n *= s
+    return n, ld
+
+
+def supported(C: int, L: int, Lk: int) -> bool:
+    return C == XC and L % 128 == 0 and 0 < Lk <= LK_PAD
+
+
+def groupnorm_affine(x: T, gamma: T, beta: T, eps: float, groups: int = 32) -> T:
+    """x [B, HW.., C] 16-bit -> f32 [B, 2, C]: GroupNorm(x) = x * ab[b, 0, c] + ab[b, 1, c]."""
+    _gpu(x, gamma, beta)
+    B, C = x.shape[0], x.shape[-1]
+    rows, ld = _rows_ld(x)
+    HW = rows // B
+    nchunk = native.lib().dbir_groupnorm_nchunk(HW, C)
+    ws = torch.empty(B * (2 * C * nchunk + 2 * C), dtype=torch.float32, device=x.device)
+    ab = torch.empty((B, 2, C), dtype=torch.float32, device=x.device)
+    native.check(native.lib().dbir_groupnorm_affine(_dt(x), x.data_ptr(), ld, B, HW, C, groups, eps, gamma.data_ptr(),
+                                                    beta.data_ptr(), ws.data_ptr(), ab.data_ptr(), _stream()),
+                 "dbir_groupnorm_affine")
+    return ab
+
+
+def xf_head(x: T, ab: T, blk: XfBlock, L: int) -> Tuple[T, T, T]:
+    """x [B, .., C] (M = B * L rows), ab f32 [B, 2, C] -> h [M, C], qk [B, L, 2C], vt [B, C, L]."""
+    _gpu(x, ab)
+    M, ldx = _rows_ld(x)
+    B, C = M // L, x.shape[-1]
+    h = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    qk = torch.empty((B, L, 2 * C), dtype=x.dtype, device=x.device)
+    vt = torch.empty((B, C, L), dtype=x.dtype, device=x.device)
+    assert ab.dtype == torch.float32 and ab.is_contiguous() and tuple(ab.shape) == (B, 2, C)
+    native.check(native.lib().dbir_xf_head(_dt(x), x.data_ptr(), ldx, ab.data_ptr(), h.data_ptr(), C, qk.data_ptr(), 2 * C,
+                                           vt.data_ptr(), L, C * L, M, L, C, blk.head_stream.data_ptr(),
+                                           blk.head_stream.numel(), blk.head_prm.data_ptr(), _stream()), "dbir_xf_head")
+    return h, qk, vt
+
+
+def xf_tail(attn: T, h: T, x: T, blk: XfBlock, kf: T, vf: T, Lk: int, scale: float, L: int, out: Optional[T] = None,
+            pair_bs: int = 0, stop_after: int = 0) -> T:
+    """attn / h / x: [Ms, C] rows (x may be 4-D NHWC, any row stride); out: [M, C] rows (M = 2 Ms when pair_bs)."""
+    _gpu(attn, h, x, out, kf, vf)
+    Ms, ldo = _rows_ld(attn)
+    _, ldh = _rows_ld(h)
+    Mx, ldx = _rows_ld(x)
+    C = attn.shape[-1]
+    M = 2 * Ms if pair_bs else Ms
+    assert Mx == Ms and _rows_ld(h)[0] == Ms
+    if out is None:
+        shp = (x.shape[0] * (2 if pair_bs else 1),) + tuple(x.shape[1:])
+        out = torch.empty(shp, dtype=x.dtype, device=x.device)
+    Mo, ldout = _rows_ld(out)
+    assert Mo == M and kf.shape[0] == M // L and kf.is_contiguous() and vf.is_contiguous()
+    native.check(native.lib().dbir_xf_tail(_dt(attn), attn.data_ptr(), ldo, h.data_ptr(), ldh, x.data_ptr(), ldx,
+                                           out.data_ptr(), ldout, M, L, C, pair_bs, blk.tail_stream.data_ptr(),
+                                           blk.tail_stream.numel(), blk.tail_prm.data_ptr(), kf.data_ptr(), vf.data_ptr(),
+                                           Lk, scale, stop_after, _stream()), "dbir_xf_tail")
+    return out

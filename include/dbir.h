@@ -156,6 +156,11 @@ int dbir_groupnorm_stats(int dtype, const void* x, long long ldx, int B, int HW,
 int dbir_groupnorm_apply(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,
                          const float* beta, const float* mean_var, int B, int HW, int C, int groups, float eps, int silu,
                          void* stream);
+/* dbir_groupnorm_affine: statistics only, folded with gamma / beta into the per (sample, channel) affine map of the
+ * normalisation, scale_shift f32 [B][2][C]: y = x * scale_shift[b][0][c] + scale_shift[b][1][c] — consumed by
+ * dbir_xf_head, which applies it while it loads its activation panel (same workspace contract as dbir_groupnorm). */
+int dbir_groupnorm_affine(int dtype, const void* x, long long ldx, int B, int HW, int C, int groups, float eps,
+                          const float* gamma, const float* beta, float* workspace, float* scale_shift, void* stream);
 /* dbir_layernorm: nn.LayerNorm rows (attention.py:255-257; swinir.py:205,211,764), eps 1e-5.
  * Normalises over the first C columns; columns [C, Cpad) of y are written as zero. */
 int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,
@@ -163,6 +168,38 @@ int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, long long l
 /* dbir_softmax_rows: in-place row softmax over the first L columns of a 16-bit [rows, ld] matrix (f32 math),
  * columns [L, ld) set to zero.  Used by the single-head d=C VAE attention (vae.py:272). */
 int dbir_softmax_rows(int dtype, void* x, long long ld, long long rows, int L, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused transformer-block kernels for the 64x64 latent level, C = 320 (csrc/xformer.hip).  One SpatialTransformer
+ * (reference attention.py:334-353 around BasicTransformerBlock._forward attention.py:265-274) becomes
+ *   dbir_groupnorm_affine -> dbir_xf_head -> dbir_attention (self) -> dbir_xf_tail
+ * instead of 16 launches; the activation is processed in 128-row panels that stay in LDS across the chained GEMMs /
+ * LayerNorms / text cross-attention / GEGLU feed-forward, only the weights stream in.
+ * Weights: ONE packed stream per kernel (diffbir_amd/xformer.py: tiles of dbir_xf_tile_bytes() bytes = 20 MFMA fragment
+ * pieces of [32 rows][16 k] in LDS order + 512 B of f32 side data), dbir_xf_head_tiles() / dbir_xf_tail_tiles() tiles.
+ * prm: f32 rows of C floats — head: proj_in bias, norm1 gamma, norm1 beta; tail: attn1.to_out bias, norm2 gamma, beta,
+ * attn2.to_out bias, norm3 gamma, beta, ff.net.2 bias, proj_out bias.
+ *
+ * dbir_xf_head: x [M, C] (block input) -> h = proj_in(x * a + s) [M, C]; n = LayerNorm1(h); qk [M, 2C] = n Wq^T | n Wk^T;
+ *   vt[b, c, l] = (n Wv^T)[b * L + l, c]  (attention.py:344-345, 266, 189-200 projections).  M = B * L, L % 128 == 0.
+ * dbir_xf_tail: attn [Ms, C] (self-attention output), h [Ms, C], x [Ms, C] ->
+ *   h1 = attn Wo1^T + b + h; a = softmax(LN2(h1) Wq^T K_ctx^T * scale) V_ctx; h2 = a Wo2^T + b + h1;
+ *   h3 = (u * gelu(g)) W2^T + b + h2 with u | g = LN3(h2) W1^T + b; out [M, C] = h3 Wpo^T + b + x
+ *   (attention.py:201-216, 266-273, 19-45, 350-353).  kfrag / vfrag: text-context K / V^T of the block, per (sample,
+ *   head) in MFMA fragment order (xformer.py: pack_context_frags), Lk <= 96.
+ *   pair_bs > 0: attn / h / x hold only the DISTINCT samples [G * pair_bs] of a classifier-free-guidance batch whose
+ *   halves were identical so far (Ms = M / 2); output sample b reads source sample (b / (2 pair_bs)) * pair_bs + b % pair_bs.
+ *   stop_after (tests only, 0 in production): dump an intermediate into `out` instead — 11: h1, 1: LN2(h1), 2: q,
+ *   3: cross-attention output, 14: h2, 4: LN3(h2), 5: h3. */
+int dbir_xf_tile_bytes(void);
+int dbir_xf_head_tiles(void);
+int dbir_xf_tail_tiles(void);
+int dbir_xf_head(int dtype, const void* x, long long ldx, const float* gn_scale_shift, void* h, long long ldh, void* qk,
+                 long long ldqk, void* vt, long long vt_ld, long long vt_bstride, int M, int L, int C, const void* wstream,
+                 long long wstream_bytes, const float* prm, void* stream);
+int dbir_xf_tail(int dtype, const void* attn_out, long long ldo, const void* h, long long ldh, const void* x, long long ldx,
+                 void* out, long long ldout, int M, int L, int C, int pair_bs, const void* wstream, long long wstream_bytes,
+                 const float* prm, const void* kfrag, const void* vfrag, int Lk, float scale, int stop_after, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * OpenCLIP text tower (reference diffbir/model/clip.py:37-54 -> open_clip Transformer / ResidualAttentionBlock; its

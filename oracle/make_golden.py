@@ -186,6 +186,9 @@ FULL_CONFIG_CASES = {
     "c2_spaced50_b2": ((21, 2, 512, 512), 50, "spaced", 231, {}),
     "c3_dpm20_b2": ((22, 2, 512, 512), 20, "dpm++_m2", 231, {}),
     "c4_tiled1024_spaced10": ((23, 1, 1024, 1024), 10, "spaced", 231, dict(tiled=True, tile=512, stride=256)),
+    # round 3: the BENCHMARKED shapes themselves: C2 at bench batch 8, C4 at 2048x2048 / 49 tiles
+    "c2_spaced50_b8": ((24, 8, 512, 512), 50, "spaced", 231, {}),
+    "c4_tiled2048_spaced10": ((25, 1, 2048, 2048), 10, "spaced", 231, dict(tiled=True, tile=512, stride=256)),
 }
 
 

@@ -193,6 +193,78 @@ def groupnorm_apply(x, gamma, beta, mean_var, eps, silu, out=None, groups=32):
     return out
 
 
+# ---- fused transformer block (csrc/xformer.hip): the same math from the block's UNPACKED weights -------------------
+XfBlock = real_ops.XfBlock
+pack_xf_block = real_ops.pack_xf_block
+xf_supported = real_ops.xf_supported
+
+
+def pack_context_frags(k, vt, Lk, heads):
+    """The test double keeps the text context in its natural layout (the kernel's fragment order is checked on the GPU)."""
+    return k[:, :Lk].contiguous(), vt[:, :, :Lk].contiguous()
+
+
+def groupnorm_affine(x, gamma, beta, eps, groups=32):
+    B, C = x.shape[0], x.shape[-1]
+    xf = x.float().reshape(B, -1, groups, C // groups)
+    mean = xf.mean(dim=(1, 3))
+    var = xf.var(dim=(1, 3), unbiased=False)
+    rstd = torch.rsqrt(var + eps).repeat_interleave(C // groups, dim=1)
+    a = rstd * gamma.float()[None]
+    s = beta.float()[None] - mean.repeat_interleave(C // groups, dim=1) * a
+    return torch.stack([a, s], dim=1)
+
+
+def _ln(v, g, b):
+    return F.layer_norm(v, (v.shape[-1],), g.float(), b.float(), 1e-5)
+
+
+def xf_head(x, ab, blk, L):
+    w, dt = blk.logical, x.dtype
+    C = x.shape[-1]
+    xr = x.reshape(-1, C).float()
+    B = xr.shape[0] // L
+    xn = (xr.reshape(B, L, C) * ab[:, 0][:, None] + ab[:, 1][:, None]).to(dt).reshape(-1, C)
+    h = (xn.float() @ w["proj_in.w"].float().t() + w["proj_in.b"].float()).to(dt)
+    n = _ln(h.float(), w["norm1.w"], w["norm1.b"]).to(dt).float()
+    q = (n @ w["q1.w"].float().t()).to(dt)
+    k = (n @ w["k1.w"].float().t()).to(dt)
+    v = (n @ w["v1.w"].float().t()).to(dt)
+    return h, torch.cat([q, k], dim=1).reshape(B, L, 2 * C), v.reshape(B, L, C).permute(0, 2, 1).contiguous()
+
+
+def xf_tail(attn, h, x, blk, kf, vf, Lk, scale, L, out=None, pair_bs=0, stop_after=0):
+    """kf / vf here are the test double's (k [B, Lk, C], v^T [B, C, Lk]) from pack_context_frags above."""
+    w, dt = blk.logical, attn.dtype
+    C, heads = attn.shape[-1], blk.heads
+    a, hh, xx = attn.reshape(-1, C), h.reshape(-1, C), x.reshape(-1, C)
+    if pair_bs:
+        def expand(t):
+            G = t.shape[0] // (L * pair_bs)
+            return t.reshape(G, 1, pair_bs * L, C).expand(G, 2, pair_bs * L, C).reshape(-1, C)
+        a, hh, xx = expand(a), expand(hh), expand(xx)
+    B = a.shape[0] // L
+    h1 = (a.float() @ w["out1.w"].float().t() + w["out1.b"].float() + hh.float()).to(dt)
+    n2 = _ln(h1.float(), w["norm2.w"], w["norm2.b"]).to(dt)
+    q = (n2.float() @ w["q2.w"].float().t()).to(dt)
+    qh = q.float().reshape(B, L, heads, 64).permute(0, 2, 1, 3)
+    kh = kf.float().reshape(B, Lk, heads, 64).permute(0, 2, 1, 3)
+    vh = vf.float().reshape(B, heads, 64, Lk).permute(0, 1, 3, 2)
+    ca = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(B * L, C).to(dt)
+    h2 = (ca.float() @ w["out2.w"].float().t() + w["out2.b"].float() + h1.float()).to(dt)
+    n3 = _ln(h2.float(), w["norm3.w"], w["norm3.b"]).to(dt)
+    u = n3.float() @ w["ff1.w"].float().t() + w["ff1.b"].float()
+    g = (u[:, : 4 * C] * F.gelu(u[:, 4 * C:])).to(dt)
+    h3 = (g.float() @ w["ff2.w"].float().t() + w["ff2.b"].float() + h2.float()).to(dt)
+    res = (h3.float() @ w["proj_out.w"].float().t() + w["proj_out.b"].float() + xx.float()).to(dt)
+    res = {0: res, 11: h1, 1: n2, 2: q, 3: ca, 14: h2, 4: n3, 5: h3}[stop_after]
+    if out is None:
+        shp = (x.shape[0] * (2 if pair_bs else 1),) + tuple(x.shape[1:])
+        return res.reshape(shp)
+    out.copy_(res.reshape(out.shape))
+    return out
+
+
 def layernorm(x, gamma, beta, C=None, eps=1e-5, out=None):
     Cpad = x.shape[-1]
     C = Cpad if C is None else C
@@ -352,7 +424,7 @@ def f32_nchw_to_u8_nhwc(src):
 
 _NAMES = ["linear", "linear_t", "conv3x3", "bmm_nt", "attention", "window_attention", "groupnorm", "groupnorm_stats",
           "groupnorm_apply", "layernorm", "clip_embed", "add_layernorm_f32", "causal_attention",
-          "space_to_depth2", "depth_to_space2",
+          "space_to_depth2", "depth_to_space2", "pack_context_frags", "groupnorm_affine", "xf_head", "xf_tail",
           "softmax_rows_", "add_scaled", "nchw_to_nhwc", "nhwc_to_nchw", "pixel_unshuffle", "timestep_embedding",
           "lincomb4", "spaced_step", "tile_gather", "tile_accumulate", "tile_accumulate_partial", "tile_normalize",
           "u8_to_f32_nchw", "wavelet_blur", "colorfix",

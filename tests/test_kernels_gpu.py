@@ -575,6 +575,108 @@ def test_pers_rejects_ineligible(tile):
         ops.conv3x3(x, pc, tile=tile)
 
 
+# ------------------------------------------------------------------------------------------------ fused transformer block
+def _xf_weights(seed=0, gain=1.0):
+    """Random weights of one C = 320 transformer block (f32, CPU), by the short names of xformer.pack_block."""
+    g = torch.Generator().manual_seed(seed)
+    C = 320
+    r = lambda *shape: torch.randn(*shape, generator=g)  # noqa: E731
+    w = {}
+    for n in ("proj_in", "out1", "out2", "proj_out"):
+        w[n + ".w"], w[n + ".b"] = r(C, C) * (gain / C ** 0.5), r(C) * 0.1
+    for n in ("q1", "k1", "v1", "q2"):
+        w[n + ".w"] = r(C, C) * (gain / C ** 0.5)
+    for n in ("norm1", "norm2", "norm3"):
+        w[n + ".w"], w[n + ".b"] = 1 + 0.1 * r(C), 0.1 * r(C)
+    w["ff1.w"], w["ff1.b"] = r(8 * C, C) * (gain / C ** 0.5), r(8 * C) * 0.1
+    w["ff2.w"], w["ff2.b"] = r(C, 4 * C) * (gain / (4 * C) ** 0.5), r(C) * 0.1
+    return w
+
+
+XF_STOPS = [(11, "h1"), (1, "LN2"), (2, "q"), (3, "cross-attn"), (14, "h2"), (4, "LN3"), (5, "h3"), (0, "out")]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L", [(2, 256), (9, 4096)])
+def test_xf_tail(B, L, dtype):
+    """Fused transformer tail (xformer.hip) against the f32 statement on the UNPACKED weights, phase by phase (debug dumps
+    of every intermediate: residual stream, LayerNorm outputs, q, text cross-attention, feed-forward) and end to end;
+    (9, 4096) = 288 panels: workgroups walk several panels (weight stream wraps, panel hand-over)."""
+    C, heads, Lk = 320, 5, 77
+    blk = ops.pack_xf_block(_xf_weights(), dtype, DEV)
+    attn, h = rnd(B * L, C, dtype=dtype, seed=1), rnd(B * L, C, dtype=dtype, seed=2)
+    x = rnd(B, L // 64, 64, C, dtype=dtype, seed=3)
+    k, vt = rnd(B, Lk, C, dtype=dtype, seed=4), rnd(B, C, 80, dtype=dtype, seed=5)
+    kf, vf = ops.pack_context_frags(k, vt, Lk, heads)
+    ek, ev = emu.pack_context_frags(k, vt, Lk, heads)
+    scale = 0.125
+    for code, name in XF_STOPS:
+        got = ops.xf_tail(attn, h, x, blk, kf, vf, Lk, scale, L, stop_after=code)
+        ref = emu.xf_tail(attn, h, x, blk, ek, ev, Lk, scale, L, stop_after=code)
+        # the fused kernel rounds h + b + a W^T once where the statement (as the reference) rounds twice: <= 1 ulp apart
+        check(f"xf_tail {name} B{B} L{L}", got, ref, dtype, scale=2.0)
+    full = ops.xf_tail(attn, h, x, blk, kf, vf, Lk, scale, L)
+    for it in range(3):
+        assert torch.equal(ops.xf_tail(attn, h, x, blk, kf, vf, Lk, scale, L), full), f"not reproducible ({it})"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_xf_tail_pairs_and_strided_output(dtype):
+    """Shared CFG prefix: inputs hold the distinct samples, the output the full batch with per-half text context; output
+    written into a column slice of a wider buffer (the decoder's concat buffers), nothing outside it touched."""
+    C, heads, Lk, L, G, bs = 320, 5, 77, 512, 2, 2
+    Bs, B = G * bs, 2 * G * bs
+    blk = ops.pack_xf_block(_xf_weights(seed=3), dtype, DEV)
+    attn, h = rnd(Bs * L, C, dtype=dtype, seed=1), rnd(Bs * L, C, dtype=dtype, seed=2)
+    x = rnd(Bs * L, C + 64, dtype=dtype, seed=3)[:, 8:8 + C].reshape(Bs, L, C)            # strided block input
+    k, vt = rnd(B, Lk, C, dtype=dtype, seed=4), rnd(B, C, 80, dtype=dtype, seed=5)
+    kf, vf = ops.pack_context_frags(k, vt, Lk, heads)
+    ek, ev = emu.pack_context_frags(k, vt, Lk, heads)
+    out_a = torch.zeros(B * L, C + 320, dtype=dtype, device=DEV)
+    out_b = torch.zeros(B * L, C + 320, dtype=dtype, device=DEV)
+    ops.xf_tail(attn, h, x, blk, kf, vf, Lk, 0.125, L, out=out_a[:, 320:], pair_bs=bs)
+    emu.xf_tail(attn, h, x, blk, ek, ev, Lk, 0.125, L, out=out_b[:, 320:], pair_bs=bs)
+    check("xf_tail pairs + strided out", out_a, out_b, dtype, scale=2.0)
+    halves = out_a[:, 320:].reshape(G, 2, bs * L, C)
+    assert (halves[:, 0].float() - halves[:, 1].float()).abs().max() > 1e-2   # the halves see different contexts
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L", [(2, 128), (5, 4096), (9, 4096)])
+def test_xf_head(B, L, dtype):
+    """GroupNorm statistics folded to an affine map, then the fused head: h, q | k and v^T against the f32 statement."""
+    C = 320
+    blk = ops.pack_xf_block(_xf_weights(seed=1), dtype, DEV)
+    x = (rnd(B, L // 64, 64, C, dtype=torch.float32, seed=7) * 1.5 + 0.3).to(dtype)
+    gam, bet = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=8), 0.1 * rnd(C, dtype=torch.float32, seed=9)
+    ab = ops.groupnorm_affine(x, gam, bet, 1e-6)
+    ab_ref = emu.groupnorm_affine(x, gam, bet, 1e-6)
+    check("groupnorm_affine", ab, ab_ref, torch.float32)
+    h, qk, vt = ops.xf_head(x, ab, blk, L)
+    eh, eqk, evt = emu.xf_head(x, ab, blk, L)
+    check(f"xf_head h B{B} L{L}", h, eh, dtype)
+    check(f"xf_head qk B{B} L{L}", qk, eqk, dtype, scale=2.0)
+    check(f"xf_head vt B{B} L{L}", vt, evt, dtype, scale=2.0)
+    h2, qk2, vt2 = ops.xf_head(x, ab, blk, L)
+    assert torch.equal(h, h2) and torch.equal(qk, qk2) and torch.equal(vt, vt2)
+    # the same normalisation as the two-kernel GroupNorm: x * a + s == groupnorm(x)
+    gn = ops.groupnorm(x, gam, bet, 1e-6, False)
+    aff = (x.float() * ab[:, 0][:, None, None] + ab[:, 1][:, None, None]).to(dtype)
+    check("groupnorm_affine == groupnorm", aff, gn, dtype)
+
+
+def test_xf_rejects_unsupported():
+    dtype = torch.float16
+    blk = ops.pack_xf_block(_xf_weights(), dtype, DEV)
+    attn, h = rnd(192, 320, dtype=dtype), rnd(192, 320, dtype=dtype)
+    k, vt = rnd(1, 77, 320, dtype=dtype), rnd(1, 320, 80, dtype=dtype)
+    kf, vf = ops.pack_context_frags(k, vt, 77, 5)
+    with pytest.raises(Exception):   # L = 192 is not a multiple of the 128-row panel
+        ops.xf_tail(attn, h, attn.reshape(1, 192, 320), blk, kf, vf, 77, 0.125, 192)
+    assert not ops.xf_supported(640, 1024, 77) and not ops.xf_supported(320, 192, 77) and not ops.xf_supported(320, 4096, 200)
+    assert ops.xf_supported(320, 4096, 77)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 ATT_CASES = [(2, 5, 1024, 1024), (1, 10, 256, 256), (2, 20, 64, 64), (2, 5, 1024, 77), (1, 2, 100, 77),
              (1, 1, 4096, 4096), (3, 4, 37, 200), (2, 20, 64, 77)]
