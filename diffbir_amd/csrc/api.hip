@@ -16,12 +16,17 @@ extern "C" const char* dbir_last_error(void) { return g_err; }
 extern "C" int dbir_abi_version(void) { return 2; }
 
 void dbir_attention_set_variant(int v);  // attention.hip
+void dbir_xf_set_variant(int v);         // xformer.hip
 
 extern "C" int dbir_set_option(int key, int value) {
   switch (key) {
     case DBIR_OPT_ATTN_VARIANT:
       DBIR_CHECK_ARG(value >= 2 && value <= 5, "dbir_set_option: attention variant must be 2 (default), 3 (generic kernel only), 4 / 5 (generic kernel at 4 / 3 waves per SIMD)");
       dbir_attention_set_variant(value);
+      return DBIR_OK;
+    case DBIR_OPT_XF_VARIANT:
+      DBIR_CHECK_ARG(value >= 0 && value <= 7, "dbir_set_option: fused-transformer staging variant must be 0 .. 7");
+      dbir_xf_set_variant(value);
       return DBIR_OK;
   }
   dbir_set_error("dbir_set_option: unknown key %d", key);

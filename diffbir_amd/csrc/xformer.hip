@@ -75,8 +75,12 @@ __device__ __forceinline__ float4 xld_f4(__amdgpu_buffer_rsrc_t r, int voff, int
 __device__ __forceinline__ uint4 xld_u4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-__device__ __forceinline__ void xst_u4(__amdgpu_buffer_rsrc_t r, int voff, int soff, uint4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+// 16-byte stores take NO scalar offset: with an SGPR soffset hipcc's hazard recognizer assumes a buffer store has read its
+// data registers at issue and lets a VALU write of them follow immediately — on gfx950 the last lanes of each 16-lane
+// group then store the NEW value (measured: wrong h rows, lanes 12-15 / 28-31, non-reproducible).  With soffset = 0 the
+// compiler inserts the wait states itself (as it does for global_store_dwordx4).
+__device__ __forceinline__ void xst_u4(__amdgpu_buffer_rsrc_t r, int voff, uint4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
 }
 __device__ __forceinline__ void xst_u2(__amdgpu_buffer_rsrc_t r, int voff, int soff, uint2 v) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
@@ -105,6 +109,10 @@ struct XfParams {
   int Lk;  float c;                // context length, softmax scale * log2(e)
   int npanels, q, gx;              // panels, panels / workgroups per XCD
   int stop_after;                  // DEBUG (tests): dump an intermediate instead of the result, see dbir.h
+  int variant;                     // A/B (dbir_set_option DBIR_OPT_XF_VARIANT): 0 = every wave stages before its MFMAs
+  int prm_row_bytes;               // = C * 4, as a RUNTIME value: a parameter row's offset then stays in the scalar offset
+                                   // operand (a literal is folded into per-access offset VGPRs, which the compiler hoisted
+                                   // out of the panel loop and spilled: scratch reload -> wait -> load chains, 15 us per LN)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -116,6 +124,7 @@ struct XfParams {
   do {                                                                                                            \
     char* dst_ = smem + RING_OFF + s_slot * TILE_BYTES;                                                           \
     const int so_ = s_t * TILE_BYTES;                                                                             \
+    if (!(abl & 8)) {                                                                                             \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_srd, (lptr_t)(dst_ + wave * 1024), 16, w_voff, so_, 0, 0);         \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_srd, (lptr_t)(dst_ + 8192 + wave * 1024), 16, w_voff, so_ + 8192,  \
                                              0, 0);                                                               \
@@ -125,6 +134,7 @@ struct XfParams {
     } else if (wave == 4) {                                                                                       \
       if (lane < 32)                                                                                              \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_srd, (lptr_t)(dst_ + TILE_W), 16, lane16, so_ + TILE_W, 0, 0); \
+    }                                                                                                             \
     }                                                                                                             \
     ++issued;                                                                                                     \
     s_slot = (s_slot + 1 == NSLOT) ? 0 : s_slot + 1;                                                              \
@@ -151,37 +161,63 @@ struct XfParams {
     ++consumed;                                                                                                   \
   } while (0)
 
-// one tile of MFMAs: NKS k-steps; A-side fragment of k-step ks at ABASE + ks * 1024 (+ lane * 16 folded into ABASE),
-// W fragments of block jl at tbase + (ks * PSTR + WFIRST + jl) * 1024 + lane * 16; fragment reads software-pipelined one
-// k-step ahead; the refill of the ring slot freed by the barrier above is issued behind the first fragment reads
-#define XF_TILE(NKS, NJ, PSTR, ABASE, WFIRST, ACC, NTILES)                                                        \
+// A RUN of tiles = consecutive stream tiles multiplied against one operand image (a whole N = 320 GEMM, the 4 GEGLU
+// projection tiles or the 2 output tiles of a feed-forward chunk).  Fragment reads are software-pipelined one k-step
+// ahead ACROSS tile boundaries: the acquire of tile i + 1 (counted wait + workgroup barrier) sits in front of the LAST
+// k-step's MFMAs of tile i, when every fragment of tile i is already in registers, and is followed at once by the reads
+// of tile i + 1's first fragments — so the LDS latency and the barrier skew of a tile boundary hide under 5 (or 2) armed
+// MFMAs instead of standing between two tiles (measured before: 1300 - 1600 cycles per tile for 640 cycles of matrix
+// work per SIMD with the barrier at the tile boundary).  Ring invariant unchanged: at the acquire of tile t every wave
+// has completed its reads of tile t - 1 (lgkmcnt(0) in front of the barrier), so that slot is refilled right behind it.
+//   XF_RUN_BEGIN: acquire the run's first tile, refill, read its first fragments (set 0)
+//   XF_RUN_BODY : NT tiles of NKS k-steps; A-side fragment of (tile i, k-step ks) at AADDR(i, ks) (lane offset folded
+//                 in), W fragments of block jl at tbase + (ks * PSTR + WFIRST + jl) * 1024 + lane * 16
+#define XF_READ_FRAGS(SET, NJ, AADDR_, WPIECE)                                                                    \
+  if (!(abl & 32)) {                                                                                              \
+    xfr[SET] = *reinterpret_cast<const typename T::vec8*>(AADDR_);                                                \
+    _Pragma("unroll") for (int jl = 0; jl < NJ; ++jl) wfr[SET][jl] =                                              \
+        *reinterpret_cast<const typename T::vec8*>(tbase + ((WPIECE) + jl) * 1024 + lane16);                      \
+  }
+
+#define XF_RUN_ACQ(NJ, AADDR, WFIRST)                                                                             \
   do {                                                                                                            \
-    const char* ab_ = (ABASE);                                                                                    \
-    const char* wb_ = tbase + (WFIRST) * 1024 + lane16;                                                           \
-    typename T::vec8 xf_[2], wf_[2][NJ];                                                                          \
-    xf_[0] = *reinterpret_cast<const typename T::vec8*>(ab_);                                                     \
-    _Pragma("unroll") for (int jl = 0; jl < NJ; ++jl) wf_[0][jl] =                                                \
-        *reinterpret_cast<const typename T::vec8*>(wb_ + jl * 1024);                                              \
+    XF_ACQUIRE();                                                                                                 \
+    XF_READ_FRAGS(0, NJ, AADDR(0, 0), WFIRST);                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
+  } while (0)
+#define XF_RUN_BEGIN(NJ, AADDR, WFIRST, NTILES)                                                                   \
+  do {                                                                                                            \
+    XF_RUN_ACQ(NJ, AADDR, WFIRST);                                                                                \
     if (issued < total) XF_STAGE(NTILES);                                                                         \
-    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                          \
+  } while (0)
+
+#define XF_RUN_BODY(NT, NKS, NJ, PSTR, AADDR, WFIRST, ACC, NTILES)                                                \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NT; ++i) _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {           \
+      const int cur_ = (i * NKS + ks) & 1;                                                                        \
       if (ks + 1 < NKS) {                                                                                         \
-        xf_[(ks + 1) & 1] = *reinterpret_cast<const typename T::vec8*>(ab_ + (ks + 1) * 1024);                    \
-        _Pragma("unroll") for (int jl = 0; jl < NJ; ++jl) wf_[(ks + 1) & 1][jl] =                                 \
-            *reinterpret_cast<const typename T::vec8*>(wb_ + ((ks + 1) * (PSTR) + jl) * 1024);                    \
+        XF_READ_FRAGS(cur_ ^ 1, NJ, AADDR(i, ks + 1), (ks + 1) * (PSTR) + (WFIRST));                              \
+      } else if (i + 1 < NT) {                                                                                    \
+        XF_ACQUIRE();                                                                                             \
+        XF_READ_FRAGS(cur_ ^ 1, NJ, AADDR(i + 1, 0), WFIRST);                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if (issued < total) XF_STAGE(NTILES);                                                                     \
       }                                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                                          \
-      _Pragma("unroll") for (int jl = 0; jl < NJ; ++jl) ACC[jl] = T::mfma32(wf_[ks & 1][jl], xf_[ks & 1], ACC[jl]); \
+      if (!(abl & 16)) {                                                                                          \
+        _Pragma("unroll") for (int jl = 0; jl < NJ; ++jl) ACC[jl] = T::mfma32(wfr[cur_][jl], xfr[cur_], ACC[jl]); \
+      }                                                                                                           \
     }                                                                                                             \
   } while (0)
 
 // a whole N = 320, K = 320 GEMM over the panel in X: 10 tiles of (10 blocks x 2 k-steps)
+#define XF_A_X2(i, ks) (smem + (wm * XKS + 2 * (i) + (ks)) * 1024 + lane16)
+#define XF_A_X5(i, ks) (smem + (wm * XKS + 5 * (i) + (ks)) * 1024 + lane16)
+#define XF_A_GB(i, ks) (smem + GB_OFF + (wm * 4 + 2 * (i) + (ks)) * 1024 + lane16)
 #define XF_GEMM320(NTILES)                                                                                        \
   do {                                                                                                            \
-    for (int kt = 0; kt < 10; ++kt) {                                                                             \
-      XF_ACQUIRE();                                                                                               \
-      XF_TILE(2, 5, 10, smem + (wm * XKS + 2 * kt) * 1024 + lane16, 5 * wn, acc, NTILES);                         \
-    }                                                                                                             \
+    XF_RUN_BEGIN(5, XF_A_X2, 5 * wn, NTILES);                                                                     \
+    XF_RUN_BODY(10, 2, 5, 10, XF_A_X2, 5 * wn, acc, NTILES);                                                      \
   } while (0)
 
 // byte offset inside a fragment-major operand image with KST k-steps per 32-row block of the 4 consecutive columns
@@ -192,21 +228,30 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
 }
 
 // acc (f32, D[n][m] layout) -> 16-bit operand image (X or the GEGLU chunk) — 20 / 4 ds_write_b64 per lane
+// (the quad of columns 160 wn + 32 j + 8 g + 4 hi sits at xoff(wm, XKS, 160 wn + 4 hi, lq) + (2 j + g / 2) * 1024 +
+// (g % 2) * 512: one opaque lane base + literals that fold into the ds_write offset field)
 #define XF_STORE_X(ACC)                                                                                           \
   do {                                                                                                            \
+    int xb_ = xoff(wm, XKS, 160 * wn + 4 * hi, lq);                                                               \
+    XF_OPAQUE(xb_);                                                                                               \
     _Pragma("unroll") for (int j = 0; j < 5; ++j) _Pragma("unroll") for (int g = 0; g < 4; ++g) {                 \
       uint2 pk_;                                                                                                  \
       pk_.x = T::pack2(ACC[j][4 * g + 0], ACC[j][4 * g + 1]);                                                     \
       pk_.y = T::pack2(ACC[j][4 * g + 2], ACC[j][4 * g + 3]);                                                     \
-      *reinterpret_cast<uint2*>(smem + xoff(wm, XKS, 160 * wn + 32 * j + 8 * g + 4 * hi, lq)) = pk_;              \
+      *reinterpret_cast<uint2*>(smem + xb_ + (2 * j + (g >> 1)) * 1024 + (g & 1) * 512) = pk_;                    \
     }                                                                                                             \
   } while (0)
+
+// A lane-offset VGPR made opaque at its use site: "base + literal" offsets are loop-invariant, LICM hoists every one of
+// them out of the panel loop into its own VGPR (40 - 60 of them, spilled, reloaded through scratch in front of each load:
+// measured 15 us per LayerNorm); behind this no-op the literal stays next to the load and folds into its `offset:` field.
+#define XF_OPAQUE(V) asm volatile("" : "+v"(V))
 
 // accumulators := f32 row of C parameters (bias), columns of this lane
 #define XF_ACC_BIAS(PROW)                                                                                         \
   do {                                                                                                            \
     _Pragma("unroll") for (int j = 0; j < 5; ++j) _Pragma("unroll") for (int g = 0; g < 4; ++g) {                 \
-      const float4 b_ = xld_f4(prm_srd, prm_voff + (32 * j + 8 * g) * 4, (PROW) * (XC * 4));                      \
+      const float4 b_ = xld_f4(prm_srd, prm_voff + (32 * j + 8 * g) * 4, (PROW) * p.prm_row_bytes);                      \
       acc[j][4 * g + 0] = b_.x;                                                                                   \
       acc[j][4 * g + 1] = b_.y;                                                                                   \
       acc[j][4 * g + 2] = b_.z;                                                                                   \
@@ -229,7 +274,8 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
 // gemm_pers.hip); RES[j][gp] = columns [160 wn + 32 j + 8 (2 gp + hi), +8) of row (32 wm + lq)
 #define XF_RES_LOAD(RES, SRD, LD, ROW0)                                                                           \
   do {                                                                                                            \
-    const int vo_ = (int)(((32 * wm + lq) * (LD) + 160 * wn + 8 * hi) * 2);                                       \
+    int vo_ = (int)(((32 * wm + lq) * (LD) + 160 * wn + 8 * hi) * 2);                                             \
+    XF_OPAQUE(vo_);                                                                                               \
     const int so_ = (int)((long long)(ROW0) * (LD) * 2);                                                          \
     _Pragma("unroll") for (int j = 0; j < 5; ++j) _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                \
         RES[j][gp] = xld_u4(SRD, vo_ + (32 * j + 16 * gp) * 2, so_);                                              \
@@ -252,8 +298,9 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
 // round the accumulators to 16 bit and store rows with 16-byte stores (half-wave exchange as in gemm_pers.hip)
 #define XF_ROW_STORE(SRD, LD, ROW0, COL0)                                                                         \
   do {                                                                                                            \
-    const int vo_ = (int)(((32 * wm + lq) * (LD) + 160 * wn + 8 * hi) * 2);                                       \
-    const int so_ = (int)(((long long)(ROW0) * (LD) + (COL0)) * 2);                                               \
+    int vo_ = (int)(((32 * wm + lq) * (LD) + 160 * wn + 8 * hi) * 2) +                                            \
+              (int)(((long long)(ROW0) * (LD) + (COL0)) * 2);                                                     \
+    XF_OPAQUE(vo_);                                                                                               \
     _Pragma("unroll") for (int j = 0; j < 5; ++j) _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {              \
       const uint32_t ax_ = T::pack2(acc[j][8 * gp + 0], acc[j][8 * gp + 1]);                                      \
       const uint32_t ay_ = T::pack2(acc[j][8 * gp + 2], acc[j][8 * gp + 3]);                                      \
@@ -261,7 +308,7 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
       const uint32_t by_ = T::pack2(acc[j][8 * gp + 6], acc[j][8 * gp + 7]);                                      \
       const auto sx_ = __builtin_amdgcn_permlane32_swap(ax_, bx_, false, false);                                  \
       const auto sy_ = __builtin_amdgcn_permlane32_swap(ay_, by_, false, false);                                  \
-      xst_u4(SRD, vo_ + (32 * j + 16 * gp) * 2, so_, make_uint4(sx_[0], sy_[0], sx_[1], sy_[1]));                 \
+      xst_u4(SRD, vo_ + (32 * j + 16 * gp) * 2, make_uint4(sx_[0], sy_[0], sx_[1], sy_[1]));                      \
     }                                                                                                             \
   } while (0)
 
@@ -278,11 +325,13 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
     }                                                                                                             \
   } while (0)
 
-// LayerNorm over the 320 columns of every panel row, input = acc (f32 values), output (16-bit) written into X.
+// LayerNorm over the 320 columns of every panel row, input = acc (f32 values), normalised rows (16-bit) written into X.
+// NO affine map here: gamma is folded into the consuming GEMM's weights and beta into its bias on the host
+// (W diag(gamma), W beta: diffbir_amd/xformer.py) — the 40 parameter loads per lane were ~5 us of exposed L2 latency.
 // A row is spread over 80 registers of a lane, its partner lane (lane ^ 32) and the partner wave (wn ^ 1): two-pass
 // statistics (mean, then centred sum of squares) with one LDS exchange each.  The two barriers also order the
 // preceding K loop's last reads of X before the writes below.
-#define XF_LAYERNORM_TO_X(GROW, BROW)                                                                            \
+#define XF_LAYERNORM_TO_X()                                                                                       \
   do {                                                                                                            \
     float* red_ = reinterpret_cast<float*>(smem + GB_OFF);                                                        \
     const int row_ = 32 * wm + lq;                                                                                \
@@ -301,13 +350,13 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
     if (hi == 0) red_[2 * XBM + wn * XBM + row_] = q_;                                                            \
     xbarrier();                                                                                                   \
     const float rstd_ = rsqrtf((red_[2 * XBM + row_] + red_[3 * XBM + row_]) * (1.0f / XC) + 1e-5f);              \
+    int xb_ = xoff(wm, XKS, 160 * wn + 4 * hi, lq);                                                               \
+    XF_OPAQUE(xb_);                                                                                               \
     _Pragma("unroll") for (int j = 0; j < 5; ++j) _Pragma("unroll") for (int g = 0; g < 4; ++g) {                 \
-      const float4 gm_ = xld_f4(prm_srd, prm_voff + (32 * j + 8 * g) * 4, (GROW) * (XC * 4));                     \
-      const float4 bt_ = xld_f4(prm_srd, prm_voff + (32 * j + 8 * g) * 4, (BROW) * (XC * 4));                     \
       uint2 pk_;                                                                                                  \
-      pk_.x = T::pack2(acc[j][4 * g + 0] * rstd_ * gm_.x + bt_.x, acc[j][4 * g + 1] * rstd_ * gm_.y + bt_.y);     \
-      pk_.y = T::pack2(acc[j][4 * g + 2] * rstd_ * gm_.z + bt_.z, acc[j][4 * g + 3] * rstd_ * gm_.w + bt_.w);     \
-      *reinterpret_cast<uint2*>(smem + xoff(wm, XKS, 160 * wn + 32 * j + 8 * g + 4 * hi, lq)) = pk_;              \
+      pk_.x = T::pack2(acc[j][4 * g + 0] * rstd_, acc[j][4 * g + 1] * rstd_);                                     \
+      pk_.y = T::pack2(acc[j][4 * g + 2] * rstd_, acc[j][4 * g + 3] * rstd_);                                     \
+      *reinterpret_cast<uint2*>(smem + xb_ + (2 * j + (g >> 1)) * 1024 + (g & 1) * 512) = pk_;                    \
     }                                                                                                             \
   } while (0)
 
@@ -319,8 +368,7 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
       const int piece_ = q_ >> 6, l_ = q_ & 63;                                                                   \
       const int rb_ = piece_ / XKS, ks_ = piece_ - rb_ * XKS;                                                     \
       const uint4 v_ = *reinterpret_cast<const uint4*>(smem + q_ * 16);                                           \
-      xst_u4(out_srd, (int)(((rb_ * 32 + (l_ & 31)) * p.ldout + ks_ * 16 + (l_ >> 5) * 8) * 2),                   \
-             (int)(row0 * p.ldout * 2), v_);                                                                      \
+      xst_u4(out_srd, (int)(((row0 + rb_ * 32 + (l_ & 31)) * p.ldout + ks_ * 16 + (l_ >> 5) * 8) * 2), v_);       \
     }                                                                                                             \
     xbarrier();                                                                                                   \
   } while (0)
@@ -349,10 +397,21 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
     }                                                                                                             \
   } while (0)
 
+// DEBUG anatomy (stop_after == 99, debug instantiation only): s_memtime per section, summed over this workgroup's panels,
+// written by wave 0 as 16 x u64 per workgroup into `out` (tools/xf_anatomy.py)
+#define XF_TS(I)                                                        \
+  do {                                                                  \
+    if (DBG == 2) {                                                     \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+      ta[I] += now_ - tprev;                                            \
+      tprev = now_;                                                     \
+    }                                                                   \
+  } while (0)
+
 // ===============================================================================================================
 // xf_tail
 // ===============================================================================================================
-template <typename T, bool DBG>
+template <typename T, int DBG>  // 0 = production, 1 = intermediate dumps (tests), 2 = section timing (tools/xf_anatomy.py)
 __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -378,7 +437,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
   const __amdgpu_buffer_rsrc_t h_srd = xsrd(p.h, ((src_rows - 1) * p.ldh + XC) * 2);
   const __amdgpu_buffer_rsrc_t x_srd = xsrd(p.x, ((src_rows - 1) * p.ldx + XC) * 2);
   const __amdgpu_buffer_rsrc_t out_srd = xsrd(p.out, (((long long)p.M - 1) * p.ldout + XC) * 2);
-  const __amdgpu_buffer_rsrc_t prm_srd = xsrd(p.prm, 8 * XC * 4);
+  const __amdgpu_buffer_rsrc_t prm_srd = xsrd(p.prm, 5 * XC * 4);
   const long long nsamp = (long long)p.M / p.L;
   const __amdgpu_buffer_rsrc_t kf_srd = xsrd(p.kf, nsamp * XHEADS * (XKB * 4) * 1024);
   const __amdgpu_buffer_rsrc_t vf_srd = xsrd(p.vf, nsamp * XHEADS * (2 * 6) * 1024);
@@ -388,11 +447,16 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
 
   int issued = 0, consumed = 0, landed = 0, s_slot = 0, c_slot = 0, s_t = 0;
   const char* tbase = smem;
+  // ablation instantiations (wall-clock A/B, tools/xf_anatomy.py): 3 = no staging, 4 = no MFMAs, 5 = no fragment reads
+  constexpr int abl = DBG == 3 ? 8 : (DBG == 4 ? 16 : (DBG == 5 ? 32 : 0));
   XF_STAGE(TAIL_TILES);
   XF_STAGE(TAIL_TILES);
 
   f32x16 acc[5];
+  typename T::vec8 xfr[2] = {}, wfr[2][5] = {};
   uint2 hres[5][4];
+  unsigned long long ta[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  if (DBG == 2) tprev = __builtin_amdgcn_s_memtime();
 
   for (int pi = 0; pi < nmine; ++pi) {
     const int panel = x0 + loc + pi * p.gx;
@@ -414,49 +478,69 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
     }
     xwait<0>();
     landed = issued;
+    XF_TS(0);
     // ---------------- phase 1: h1 = attn @ Wo1^T + b + h;  X = LayerNorm2(h1) ----------------
     XF_GEMM320(TAIL_TILES);
+    XF_TS(1);
     XF_ROUND_TO_HRES();
-    if (DBG && p.stop_after == 11) { XF_DUMP_HRES(); XF_SKIP_REST(TAIL_TILES); continue; }
-    XF_LAYERNORM_TO_X(1, 2);
+    if (DBG == 1 && p.stop_after == 11) { XF_DUMP_HRES(); XF_SKIP_REST(TAIL_TILES); continue; }
+    XF_LAYERNORM_TO_X();
+    XF_ACC_BIAS(1);  // q = LN2(h1) Wq^T: beta2 Wq^T (the folded LayerNorm shift) is the accumulators' initial value
     xwait<0>();
     landed = issued;
-    if (DBG && p.stop_after == 1) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
+    if (DBG == 1 && p.stop_after == 1) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
+    XF_TS(2);
     // ---------------- phase 2: q = LN2(h1) @ Wq^T  -> X ----------------
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     XF_GEMM320(TAIL_TILES);
+    XF_TS(3);
+    uint4 kfr[12];  // context K fragments of this wave's first cross-attention unit (rowblk wave / 5, head wave % 5)
+    {
+      const int kf_so = (b * XHEADS + wave % XHEADS) * (XKB * 4) * 1024;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) kfr[i] = xld_u4(kf_srd, lane16, kf_so + i * 1024);
+    }
     xbarrier();  // all waves are done reading X
     XF_STORE_X(acc);
-    if (DBG && p.stop_after == 2) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
+    if (DBG == 1 && p.stop_after == 2) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
     xbarrier();
+    XF_TS(4);
     // ---------------- phase 3: text cross-attention, all heads, in place in X ----------------
+    // (K fragments of a unit are fetched one unit ahead — the first ones under the q store above — and V^T fragments
+    // behind the S^T MFMAs, under the softmax arithmetic: the loads are L2 hits of ~1 us that stood in front of every
+    // MFMA group before: 13 us per panel)
     for (int u = wave; u < 4 * XHEADS; u += 8) {
       const int rb = u / XHEADS, hd = u - rb * XHEADS;
       typename T::vec8 qf[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         qf[ks] = *reinterpret_cast<const typename T::vec8*>(smem + (rb * XKS + 4 * hd + ks) * 1024 + lane16);
-      const int kf_so = (b * XHEADS + hd) * (XKB * 4) * 1024, vf_so = (b * XHEADS + hd) * (2 * 6) * 1024;
+      const int vf_so = (b * XHEADS + hd) * (2 * 6) * 1024;
+      int hi4 = 4 * hi, ob = xoff(rb, XKS, 64 * hd + 4 * hi, lq);  // opaque: keeps the 48 key compares / 8 store offsets
+      XF_OPAQUE(hi4);                                              // of a unit from being hoisted out of the panel loop
+      XF_OPAQUE(ob);
       f32x16 s_acc[XKB];
 #pragma unroll
       for (int kb = 0; kb < XKB; ++kb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const uint4 kv = xld_u4(kf_srd, lane16 + (kb * 4 + ks) * 1024, kf_so);
-          s_acc[kb] = T::mfma32(__builtin_bit_cast(typename T::vec8, kv), qf[ks], s_acc[kb]);
-        }
+        for (int ks = 0; ks < 4; ++ks)
+          s_acc[kb] = T::mfma32(__builtin_bit_cast(typename T::vec8, kfr[kb * 4 + ks]), qf[ks], s_acc[kb]);
+      }
+      uint4 vfr[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) vfr[i] = xld_u4(vf_srd, lane16, vf_so + i * 1024);
+      if (u + 8 < 4 * XHEADS) {  // next unit of this wave: (u + 8) % 5 = (hd + 3) % 5
+        const int kf_so = (b * XHEADS + (u + 8) % XHEADS) * (XKB * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kfr[i] = xld_u4(kf_srd, lane16, kf_so + i * 1024);
       }
       float mx = -1e30f;
 #pragma unroll
       for (int kb = 0; kb < XKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + hi4;
           const float sv = key < p.Lk ? s_acc[kb][r] : -1e30f;
           s_acc[kb][r] = sv;
           mx = fmaxf(mx, sv);
@@ -486,10 +570,8 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
         const uint4 pp = pack8<T>(pf);
         const typename T::vec8 pfrag = __builtin_bit_cast(typename T::vec8, pp);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const uint4 vv = xld_u4(vf_srd, lane16 + (t * 6 + s) * 1024, vf_so);
-          o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
-        }
+        for (int t = 0; t < 2; ++t)
+          o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vfr[t * 6 + s]), pfrag, o_acc[t]);
       }
       const float inv = 1.0f / psum;
 #pragma unroll
@@ -499,48 +581,54 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
           uint2 pk;
           pk.x = T::pack2(o_acc[t][4 * g + 0] * inv, o_acc[t][4 * g + 1] * inv);
           pk.y = T::pack2(o_acc[t][4 * g + 2] * inv, o_acc[t][4 * g + 3] * inv);
-          *reinterpret_cast<uint2*>(smem + xoff(rb, XKS, 64 * hd + 32 * t + 8 * g + 4 * hi, lq)) = pk;
+          *reinterpret_cast<uint2*>(smem + ob + (2 * t + (g >> 1)) * 1024 + (g & 1) * 512) = pk;
         }
     }
+    XF_TS(5);
     // acc = h1 + b_out2 (the K / V fragment loads above are ordinary loads: drain, then the ring is known landed)
+    XF_ACC_BIAS(2);
+    XF_ACC_ADD_HRES();
+    xwait<0>();
+    landed = issued;
+    if (DBG == 1 && p.stop_after == 3) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
+    XF_TS(6);
+    // ---------------- phase 4: h2 = a @ Wo2^T + b + h1;  X = LayerNorm3(h2) ----------------
+    XF_GEMM320(TAIL_TILES);
+    XF_TS(7);
+    XF_ROUND_TO_HRES();
+    if (DBG == 1 && p.stop_after == 14) { XF_DUMP_HRES(); XF_SKIP_REST(TAIL_TILES); continue; }
+    XF_LAYERNORM_TO_X();
+    // acc = h2 + b_ff2
     XF_ACC_BIAS(3);
     XF_ACC_ADD_HRES();
     xwait<0>();
     landed = issued;
-    if (DBG && p.stop_after == 3) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
-    // ---------------- phase 4: h2 = a @ Wo2^T + b + h1;  X = LayerNorm3(h2) ----------------
-    XF_GEMM320(TAIL_TILES);
-    XF_ROUND_TO_HRES();
-    if (DBG && p.stop_after == 14) { XF_DUMP_HRES(); XF_SKIP_REST(TAIL_TILES); continue; }
-    XF_LAYERNORM_TO_X(4, 5);
-    // acc = h2 + b_ff2
-    XF_ACC_BIAS(6);
-    XF_ACC_ADD_HRES();
-    xwait<0>();
-    landed = issued;
-    if (DBG && p.stop_after == 4) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
+    if (DBG == 1 && p.stop_after == 4) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
+    XF_TS(8);
     // ---------------- phase 5: GEGLU feed-forward, 20 chunks of 64 hidden units ----------------
     for (int cch = 0; cch < XCH; ++cch) {
       f32x16 gacc[2];
+      XF_RUN_ACQ(2, XF_A_X5, 2 * wn);
+      {  // G := GEGLU projection bias (f32 side data of the chunk's first tile): [wn][value | gate][32]
+        const float* bz = reinterpret_cast<const float*>(tbase + TILE_W) + wn * 64 + 4 * hi;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        XF_ACQUIRE();
-        if (i == 0) {  // G := GEGLU projection bias (f32 side data of the chunk's first tile): [wn][value | gate][32]
-          const float* bz = reinterpret_cast<const float*>(tbase + TILE_W) + wn * 64 + 4 * hi;
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-          for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const float4 b_ = *reinterpret_cast<const float4*>(bz + blk * 32 + 8 * g);
-              gacc[blk][4 * g + 0] = b_.x;
-              gacc[blk][4 * g + 1] = b_.y;
-              gacc[blk][4 * g + 2] = b_.z;
-              gacc[blk][4 * g + 3] = b_.w;
-            }
-        }
-        XF_TILE(5, 2, 4, smem + (wm * XKS + 5 * i) * 1024 + lane16, 2 * wn, gacc, TAIL_TILES);
+          for (int g = 0; g < 4; ++g) {
+            const float4 b_ = *reinterpret_cast<const float4*>(bz + blk * 32 + 8 * g);
+            gacc[blk][4 * g + 0] = b_.x;
+            gacc[blk][4 * g + 1] = b_.y;
+            gacc[blk][4 * g + 2] = b_.z;
+            gacc[blk][4 * g + 3] = b_.w;
+          }
       }
+      if (issued < total) XF_STAGE(TAIL_TILES);  // (behind the side-data reads: hipcc drains vmcnt in front of an LDS read
+                                                 // that follows a direct-to-LDS load it cannot tell apart from the ring)
+      XF_RUN_BODY(4, 5, 2, 4, XF_A_X5, 2 * wn, gacc, TAIL_TILES);
+      XF_TS(9);
       // g = value * gelu(gate) -> GEGLU chunk image [rowblk 4][kstep 4] (its previous readers passed a barrier since)
+      int gb = GB_OFF + xoff(wm, 4, 32 * wn + 4 * hi, lq);
+      XF_OPAQUE(gb);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float v[4];
@@ -549,28 +637,34 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
         uint2 pk;
         pk.x = T::pack2(v[0], v[1]);
         pk.y = T::pack2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(smem + GB_OFF + xoff(wm, 4, 32 * wn + 8 * g + 4 * hi, lq)) = pk;
+        *reinterpret_cast<uint2*>(smem + gb + (g >> 1) * 1024 + (g & 1) * 512) = pk;
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        XF_ACQUIRE();  // its barrier publishes the chunk
-        XF_TILE(2, 5, 10, smem + GB_OFF + (wm * 4 + 2 * i) * 1024 + lane16, 5 * wn, acc, TAIL_TILES);
-      }
+      XF_TS(10);
+      XF_RUN_BEGIN(5, XF_A_GB, 5 * wn, TAIL_TILES);  // its barrier publishes the chunk
+      XF_RUN_BODY(2, 2, 5, 10, XF_A_GB, 5 * wn, acc, TAIL_TILES);
+      XF_TS(11);
     }
     // ---------------- phase 6: h3 -> X; acc = x + b_po; out = h3 @ Wpo^T + ... ----------------
     xbarrier();  // all waves are done reading X (LN3 output) — the last FF1 tile was many barriers ago, kept for clarity
     XF_STORE_X(acc);
-    if (DBG && p.stop_after == 5) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
+    if (DBG == 1 && p.stop_after == 5) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
     {
       uint4 res[5][2];
       XF_RES_LOAD(res, x_srd, p.ldx, srow0);
-      XF_ACC_BIAS(7);
+      XF_ACC_BIAS(4);
       XF_ACC_ADD_RES(res);
     }
     xwait<0>();
     landed = issued;
+    XF_TS(12);
     XF_GEMM320(TAIL_TILES);
+    XF_TS(13);
     XF_ROW_STORE(out_srd, p.ldout, row0, 0);
+    XF_TS(14);
+  }
+  if (DBG == 2 && wave == 0 && lane == 0) {  // (the timing build's section table goes to the tensor passed as `h`)
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<u16*>(p.h)) + (long long)blockIdx.x * 16;
+    for (int i = 0; i < 16; ++i) dbg[i] = ta[i];
   }
 #endif
 }
@@ -603,13 +697,14 @@ __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
 
   int issued = 0, consumed = 0, landed = 0, s_slot = 0, c_slot = 0, s_t = 0;
   const char* tbase = smem;
+  constexpr int abl = 0;
   XF_STAGE(HEAD_TILES);
   XF_STAGE(HEAD_TILES);
 
   const __amdgpu_buffer_rsrc_t xin_srd = xsrd(p.o, (((long long)p.M - 1) * p.ldo + XC) * 2);
   const __amdgpu_buffer_rsrc_t h_srd = xsrd(p.h, (((long long)p.M - 1) * p.ldh + XC) * 2);
   const __amdgpu_buffer_rsrc_t out_srd = xsrd(p.out, (((long long)p.M - 1) * p.ldout + 2 * XC) * 2);
-  const __amdgpu_buffer_rsrc_t prm_srd = xsrd(p.prm, 3 * XC * 4);
+  const __amdgpu_buffer_rsrc_t prm_srd = xsrd(p.prm, 4 * XC * 4);
   const long long nsamp = (long long)p.M / p.L;
   const __amdgpu_buffer_rsrc_t ab_srd = xsrd(p.ab, nsamp * 2 * XC * 4);
   const __amdgpu_buffer_rsrc_t vt_srd = xsrd(p.vt, ((nsamp - 1) * p.vt_bs + (long long)(XC - 1) * p.vt_ld + p.L) * 2);
@@ -617,6 +712,7 @@ __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
   const int xin_voff = (int)((lq * p.ldo + hi * 8) * 2);
 
   f32x16 acc[5];
+  typename T::vec8 xfr[2], wfr[2][5];
 
   for (int pi = 0; pi < nmine; ++pi) {
     const int panel = x0 + loc + pi * p.gx;
@@ -652,26 +748,20 @@ __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
     for (int j = 0; j < 5; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = T::to_f32(T::from_f32(acc[j][r]));
-    XF_LAYERNORM_TO_X(1, 2);
+    XF_LAYERNORM_TO_X();
     xwait<0>();
     landed = issued;
-    // ---------------- phase 2 / 3: q, k (no bias) -> out[:, 0:C], out[:, C:2C] ----------------
+    // ---------------- phase 2 / 3: q, k (bias = the folded LayerNorm shift) -> out[:, 0:C], out[:, C:2C] ----------------
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      XF_ACC_BIAS(1 + part);
       XF_GEMM320(HEAD_TILES);
       XF_ROW_STORE(out_srd, p.ldout, row0, part * XC);
       xwait<0>();
       landed = issued;
     }
     // ---------------- phase 4: v -> transposed through LDS -> v^T[b, c, l0 .. l0 + 128) ----------------
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    XF_ACC_BIAS(3);
     XF_GEMM320(HEAD_TILES);
     xbarrier();  // all waves are done reading X: reuse it as the [320 channels][128 rows] transpose buffer
     {
@@ -688,7 +778,7 @@ __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
       for (int q = tid; q < XC * (XBM / 8); q += XNT) {
         const int n = q >> 4, mc = q & 15;
         const uint4 v = *reinterpret_cast<const uint4*>(ts + n * XBM + mc * 8);
-        xst_u4(vt_srd, (int)((n * p.vt_ld + mc * 8) * 2), vt_so, v);
+        xst_u4(vt_srd, (int)((n * p.vt_ld + mc * 8) * 2) + vt_so, v);
       }
     }
     xwait<0>();
@@ -696,6 +786,8 @@ __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
   }
 #endif
 }
+
+int g_xf_variant = 1;
 
 int xf_grid(int npanels, int* q, int* gx) {
   *q = cdiv(npanels, 8);
@@ -709,6 +801,8 @@ int xf_set_lds(KT kern) {
 }
 
 }  // namespace
+
+void dbir_xf_set_variant(int v) { g_xf_variant = v; }
 
 extern "C" int dbir_xf_tile_bytes(void) { return TILE_BYTES; }
 extern "C" int dbir_xf_tail_tiles(void) { return TAIL_TILES; }
@@ -747,23 +841,33 @@ extern "C" int dbir_xf_tail(int dtype, const void* attn_out, long long ldo, cons
   p.Lk = Lk; p.c = scale * 1.4426950408889634f;
   p.npanels = M / XBM;
   p.stop_after = stop_after;
+  p.variant = g_xf_variant;
+  p.prm_row_bytes = XC * 4;
   const int grid = xf_grid(p.npanels, &p.q, &p.gx);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr_set = false;
   if (!attr_set) {
-    if (xf_set_lds(&xf_tail_kernel<F16, false>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, false>) != 0 ||
-        xf_set_lds(&xf_tail_kernel<F16, true>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, true>) != 0) {
+    if (xf_set_lds(&xf_tail_kernel<F16, 0>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 0>) != 0 ||
+        xf_set_lds(&xf_tail_kernel<F16, 1>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 1>) != 0 ||
+        xf_set_lds(&xf_tail_kernel<F16, 2>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 3>) != 0 ||
+        xf_set_lds(&xf_tail_kernel<F16, 4>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 5>) != 0) {
       dbir_set_error("dbir_xf_tail: cannot reserve %d bytes of LDS", XF_LDS);
       return DBIR_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  if (stop_after) {  // debug instantiation (tests): intermediate dumps
-    if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, true>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-    else hipLaunchKernelGGL((xf_tail_kernel<BF16, true>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+  if (stop_after >= 99) {  // section timing (99) / ablations (103 - 105), f16 only, results meaningless
+    DBIR_CHECK_ARG(dtype == DBIR_F16, "dbir_xf_tail: the timing instantiations are f16 only");
+    if (stop_after == 99) hipLaunchKernelGGL((xf_tail_kernel<F16, 2>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else if (stop_after == 103) hipLaunchKernelGGL((xf_tail_kernel<F16, 3>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else if (stop_after == 104) hipLaunchKernelGGL((xf_tail_kernel<F16, 4>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else hipLaunchKernelGGL((xf_tail_kernel<F16, 5>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+  } else if (stop_after) {  // debug instantiation (tests): intermediate dumps
+    if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, 1>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else hipLaunchKernelGGL((xf_tail_kernel<BF16, 1>), dim3(grid), dim3(XNT), XF_LDS, s, p);
   } else {
-    if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, false>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-    else hipLaunchKernelGGL((xf_tail_kernel<BF16, false>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, 0>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else hipLaunchKernelGGL((xf_tail_kernel<BF16, 0>), dim3(grid), dim3(XNT), XF_LDS, s, p);
   }
   DBIR_CHECK_LAUNCH("dbir_xf_tail");
   return DBIR_OK;
@@ -798,6 +902,8 @@ extern "C" int dbir_xf_head(int dtype, const void* x, long long ldx, const float
   p.M = M; p.L = L;
   p.wstream = wstream; p.prm = prm;
   p.npanels = M / XBM;
+  p.variant = g_xf_variant;
+  p.prm_row_bytes = XC * 4;
   const int grid = xf_grid(p.npanels, &p.q, &p.gx);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr_set = false;

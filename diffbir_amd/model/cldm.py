@@ -155,6 +155,9 @@ class ControlLDM:
         they build for classifier-free guidance (identical x / t / c_img in both halves; model/unet.py docstring)."""
         c_txt, c_img = cond["c_txt"], cond["c_img"]
         pair = cond.get("cfg_pair")
+        th = cond.get("t_host")  # engine extension: all elements of t equal this host scalar (time-embedding cache)
+        if th is not None and os.environ.get("DBIR_CHECK_CFG_PAIR"):
+            assert bool((t.float() == float(th)).all()), "t_host set on a batch with other timesteps"
         if pair is not None and os.environ.get("DBIR_CHECK_CFG_PAIR"):
             G, bs = pair
             for v in (x_noisy, t, c_img):
@@ -166,8 +169,8 @@ class ControlLDM:
         if os.environ.get("DBIR_FUSE_CONTROL", "1") == "0":
             return self._forward_eager_unfused(x_noisy, t, c_txt, c_img, pair)
         if not (self.overlap_streams and x_noisy.is_cuda):
-            feats = cn.features(x_noisy, c_img, t, c_txt, pair=pair)
-            return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, pair=pair,
+            feats = cn.features(x_noisy, c_img, t, c_txt, pair=pair, t_host=th)
+            return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, pair=pair, t_host=th,
                              control_feats=(feats, cn.zero, self.control_scales))
         main = torch.cuda.current_stream()
         side = self._side_stream.get(x_noisy.device)
@@ -175,12 +178,12 @@ class ControlLDM:
             side = self._side_stream[x_noisy.device] = torch.cuda.Stream(device=x_noisy.device)
         side.wait_stream(main)                      # inputs produced on the main stream are ready
         with torch.cuda.stream(side):
-            feats = cn.features(x_noisy, c_img, t, c_txt, pair=pair)
+            feats = cn.features(x_noisy, c_img, t, c_txt, pair=pair, t_host=th)
             done = torch.cuda.Event()
             done.record(side)
         for c in feats:                             # allocated on `side`, consumed (and later freed) on `main`
             c.record_stream(main)
-        return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, control_ready=done, pair=pair,
+        return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, control_ready=done, pair=pair, t_host=th,
                          control_feats=(feats, cn.zero, self.control_scales))
 
     def _forward_eager_unfused(self, x_noisy: T, t: T, c_txt: T, c_img: T, pair) -> T:

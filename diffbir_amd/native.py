@@ -105,6 +105,9 @@ def lib() -> ctypes.CDLL:
         v = os.environ.get("DBIR_ATTN_VARIANT")  # A/B switch (include/dbir.h DBIR_OPT_ATTN_VARIANT)
         if v:
             check(l.dbir_set_option(1, int(v)), "dbir_set_option")
+        v = os.environ.get("DBIR_XF_VARIANT")    # A/B switch (DBIR_OPT_XF_VARIANT)
+        if v:
+            check(l.dbir_set_option(2, int(v)), "dbir_set_option")
     return _lib
 
 

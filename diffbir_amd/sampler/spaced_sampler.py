@@ -95,6 +95,9 @@ class SpacedSampler(Sampler):
             ti = total - i - 1
             model_t = torch.full((bs,), int(step), device=device, dtype=torch.float32)
             s = self.get_cfg_scale(cfg_scale, int(step))
+            cond["t_host"] = float(int(step))  # engine extension: every element of model_t is this host scalar
+            if use_cfg:
+                cond2["t_host"] = cond["t_host"]
             if use_cfg and s != 1.0:
                 o = fwd(torch.cat([x, x], dim=0), torch.cat([model_t, model_t]), cond2)
                 ou, oc = o[:bs], o[bs:]

@@ -11,6 +11,10 @@ one flat sequence of tiles; this module lays that sequence out.  A tile is 20 "f
 MFMA 32x32x16 operand fragment is read: lane = 32 * hi + lq owns row 32 j + lq, columns 16 s + 8 hi .. + 8 — followed by
 512 B of f32 side data (the GEGLU projection bias of a feed-forward chunk).  Tile order = consumption order:
 
+The LayerNorm affine maps are folded into the GEMMs that consume the normalised rows — (xhat gamma + beta) W^T =
+xhat (W diag(gamma))^T + W beta: to_q / to_k / to_v (norm1), attn2.to_q (norm2) and ff.net.0.proj (norm3) are stored
+column-scaled, the W beta rows are the accumulators' initial values (parameter rows / the chunk's side data).
+
   head: proj_in, to_q, to_k, to_v                      10 tiles each: K tile kt = pieces [k-step 2 kt + ksl][block j]
   tail: attn1.to_out, attn2.to_q, attn2.to_out         10 tiles each, as above
         20 feed-forward chunks of 64 hidden units c:   4 tiles of ff.net.0.proj rows (value, gate blocks interleaved per
@@ -38,9 +42,9 @@ LK_PAD = 96
 class XfBlock:
     """Packed weights of one transformer block for xf_head / xf_tail."""
     head_stream: T          # uint8 [HEAD_TILES, TILE_BYTES]
-    head_prm: T             # f32 [3, C]: proj_in bias, norm1 gamma, norm1 beta
+    head_prm: T             # f32 [4, C]: proj_in bias, then W beta1 for to_q / to_k / to_v (LayerNorm1 folded)
     tail_stream: T          # uint8 [TAIL_TILES, TILE_BYTES]
-    tail_prm: T             # f32 [8, C]
+    tail_prm: T             # f32 [5, C]: to_out1 bias, Wq2 beta2, to_out2 bias, ff.net.2 bias, proj_out bias
     heads: int
     logical: Dict[str, T]   # the unpacked 16-bit weights / f32 vectors (validation tools and the CPU test double)
 
@@ -83,16 +87,21 @@ def pack_block(w: Dict[str, T], dtype, device) -> XfBlock:
     g = {k: v.detach().float().cpu().reshape(v.shape[0], -1) if v.dim() > 1 else v.detach().float().cpu() for k, v in w.items()}
     C = g["proj_in.w"].shape[0]
     assert C == XC and g["ff2.w"].shape == (C, 4 * C), "fused transformer kernels are built for C = 320"
-    head_prm = torch.stack([g["proj_in.b"], g["norm1.w"], g["norm1.b"]]).contiguous().to(device)
-    tail_prm = torch.stack([g["out1.b"], g["norm2.w"], g["norm2.b"], g["out2.b"], g["norm3.w"], g["norm3.b"],
-                            g["ff2.b"], g["proj_out.b"]]).contiguous().to(device)
+    # LayerNorm affine maps folded into the consuming GEMMs: (xhat * gamma + beta) W^T = xhat (W diag(gamma))^T + W beta
+    fold = lambda wn, nn: (g[wn] * g[nn + ".w"][None, :], g[wn] @ g[nn + ".b"])  # noqa: E731
+    (q1w, q1b), (k1w, k1b), (v1w, v1b) = fold("q1.w", "norm1"), fold("k1.w", "norm1"), fold("v1.w", "norm1")
+    q2w, q2b = fold("q2.w", "norm2")
+    ff1w, ff1b = fold("ff1.w", "norm3")
+    ff1b = ff1b + g["ff1.b"]
+    head_prm = torch.stack([g["proj_in.b"], q1b, k1b, v1b]).contiguous().to(device)
+    tail_prm = torch.stack([g["out1.b"], q2b, g["out2.b"], g["ff2.b"], g["proj_out.b"]]).contiguous().to(device)
     logical = {k: (v.to(dtype) if k.endswith(".w") and not k.startswith("norm") else v).to(device) for k, v in g.items()}
     if torch.empty(0, dtype=dtype).element_size() != 2:  # f32 test double (CPU wiring tests): no kernel streams
         e = torch.empty((0, TILE_BYTES), dtype=torch.uint8, device=device)
         return XfBlock(e, head_prm, e, tail_prm, C // 64, logical)
     h = lambda name: g[name].to(dtype)  # noqa: E731  (weights are rounded to the 16-bit compute type once, here)
-    head = torch.cat([_tiles_n320(h(n)) for n in ("proj_in.w", "q1.w", "k1.w", "v1.w")])
-    w1, b1 = _geglu_interleave(g["ff1.w"], g["ff1.b"])
+    head = torch.cat([_tiles_n320(t.to(dtype)) for t in (g["proj_in.w"], q1w, k1w, v1w)])
+    w1, b1 = _geglu_interleave(ff1w, ff1b)
     p1 = _pieces(w1.to(dtype))                      # [80 blocks, 20 k-steps, 64, 8]
     p2 = _pieces(h("ff2.w"))                        # [10 blocks, 80 k-steps, 64, 8]
     ff_tiles, ff_aux = [], []
@@ -103,7 +112,7 @@ def pack_block(w: Dict[str, T], dtype, device) -> XfBlock:
         for i in range(2):                          # piece = ksl * 10 + j
             ff_tiles.append(p2[:, 4 * c + 2 * i:4 * c + 2 * i + 2].permute(1, 0, 2, 3).reshape(20, 64, 8))
             ff_aux.append(torch.zeros(128))
-    tail = torch.cat([_tiles_n320(h("out1.w")), _tiles_n320(h("q2.w")), _tiles_n320(h("out2.w")),
+    tail = torch.cat([_tiles_n320(h("out1.w")), _tiles_n320(q2w.to(dtype)), _tiles_n320(h("out2.w")),
                       torch.stack(ff_tiles), _tiles_n320(h("proj_out.w"))])
     tail_aux = torch.cat([torch.zeros(30, 128), torch.stack(ff_aux), torch.zeros(10, 128)])
     assert head.shape[0] == HEAD_TILES and tail.shape[0] == TAIL_TILES

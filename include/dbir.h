@@ -39,6 +39,9 @@ int dbir_abi_version(void);
 /* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 2 (default) = LDS-resident
  * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape. */
 #define DBIR_OPT_ATTN_VARIANT 1
+/* DBIR_OPT_XF_VARIANT: weight staging schedule of dbir_xf_head / dbir_xf_tail — 1 (default) = the two wave groups stage
+ * their shares of a tile at opposite ends of the tile's MFMAs, 0 = every wave stages first (A/B). */
+#define DBIR_OPT_XF_VARIANT 2
 int dbir_set_option(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -177,8 +180,8 @@ int dbir_softmax_rows(int dtype, void* x, long long ld, long long rows, int L, v
  * LayerNorms / text cross-attention / GEGLU feed-forward, only the weights stream in.
  * Weights: ONE packed stream per kernel (diffbir_amd/xformer.py: tiles of dbir_xf_tile_bytes() bytes = 20 MFMA fragment
  * pieces of [32 rows][16 k] in LDS order + 512 B of f32 side data), dbir_xf_head_tiles() / dbir_xf_tail_tiles() tiles.
- * prm: f32 rows of C floats — head: proj_in bias, norm1 gamma, norm1 beta; tail: attn1.to_out bias, norm2 gamma, beta,
- * attn2.to_out bias, norm3 gamma, beta, ff.net.2 bias, proj_out bias.
+ * prm: f32 rows of C floats — head: proj_in bias, W beta1 for to_q / to_k / to_v; tail: attn1.to_out bias, Wq2 beta2,
+ * attn2.to_out bias, ff.net.2 bias, proj_out bias (the LayerNorm affine maps are folded into the consuming weights).
  *
  * dbir_xf_head: x [M, C] (block input) -> h = proj_in(x * a + s) [M, C]; n = LayerNorm1(h); qk [M, 2C] = n Wq^T | n Wk^T;
  *   vt[b, c, l] = (n Wv^T)[b * L + l, c]  (attention.py:344-345, 266, 189-200 projections).  M = B * L, L % 128 == 0.
@@ -189,8 +192,8 @@ int dbir_softmax_rows(int dtype, void* x, long long ld, long long rows, int L, v
  *   head) in MFMA fragment order (xformer.py: pack_context_frags), Lk <= 96.
  *   pair_bs > 0: attn / h / x hold only the DISTINCT samples [G * pair_bs] of a classifier-free-guidance batch whose
  *   halves were identical so far (Ms = M / 2); output sample b reads source sample (b / (2 pair_bs)) * pair_bs + b % pair_bs.
- *   stop_after (tests only, 0 in production): dump an intermediate into `out` instead — 11: h1, 1: LN2(h1), 2: q,
- *   3: cross-attention output, 14: h2, 4: LN3(h2), 5: h3. */
+ *   stop_after (tests only, 0 in production): dump an intermediate into `out` instead — 11: h1, 1: normalised h1 (no
+ *   affine), 2: q, 3: cross-attention output, 14: h2, 4: normalised h2, 5: h3; 99 / 103 - 105: timing instantiations. */
 int dbir_xf_tile_bytes(void);
 int dbir_xf_head_tiles(void);
 int dbir_xf_tail_tiles(void);

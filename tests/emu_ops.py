@@ -257,7 +257,10 @@ def xf_tail(attn, h, x, blk, kf, vf, Lk, scale, L, out=None, pair_bs=0, stop_aft
     g = (u[:, : 4 * C] * F.gelu(u[:, 4 * C:])).to(dt)
     h3 = (g.float() @ w["ff2.w"].float().t() + w["ff2.b"].float() + h2.float()).to(dt)
     res = (h3.float() @ w["proj_out.w"].float().t() + w["proj_out.b"].float() + xx.float()).to(dt)
-    res = {0: res, 11: h1, 1: n2, 2: q, 3: ca, 14: h2, 4: n3, 5: h3}[stop_after]
+    if stop_after in (1, 4):  # the kernel's operand image holds the normalised rows; the affine map lives in its weights
+        res = F.layer_norm((h1 if stop_after == 1 else h2).float(), (C,)).to(dt)
+    else:
+        res = {0: res, 11: h1, 2: q, 3: ca, 14: h2, 5: h3}[stop_after]
     if out is None:
         shp = (x.shape[0] * (2 if pair_bs else 1),) + tuple(x.shape[1:])
         return res.reshape(shp)

@@ -59,12 +59,15 @@ def test_weight_stream_is_what_the_kernel_reads():
     assert tuple(blk.head_stream.shape) == (xformer.HEAD_TILES, xformer.TILE_BYTES)
     assert tuple(blk.tail_stream.shape) == (xformer.TAIL_TILES, xformer.TILE_BYTES)
     h16 = lambda n: w[n].half().numpy()  # noqa: E731
-    for i, n in enumerate(("proj_in.w", "q1.w", "k1.w", "v1.w")):
-        assert np.array_equal(_read_gemm320(blk.head_stream, 10 * i), h16(n)), n
-    for t0, n in ((0, "out1.w"), (10, "q2.w"), (20, "out2.w"), (150, "proj_out.w")):
-        assert np.array_equal(_read_gemm320(blk.tail_stream, t0), h16(n)), n
+    # LayerNorm affine maps are folded into the consuming weights: W diag(gamma), bias W beta
+    fw = lambda n, ln: (w[n] * w[ln + ".w"][None, :]).half().numpy()  # noqa: E731
+    fb = lambda n, ln: (w[n] @ w[ln + ".b"]).numpy()                   # noqa: E731
+    for i, exp in enumerate((h16("proj_in.w"), fw("q1.w", "norm1"), fw("k1.w", "norm1"), fw("v1.w", "norm1"))):
+        assert np.array_equal(_read_gemm320(blk.head_stream, 10 * i), exp), i
+    for t0, exp in ((0, h16("out1.w")), (10, fw("q2.w", "norm2")), (20, h16("out2.w")), (150, h16("proj_out.w"))):
+        assert np.array_equal(_read_gemm320(blk.tail_stream, t0), exp), t0
     # feed-forward: chunk c = hidden units [64 c, 64 c + 64); wave column half wn owns hidden block 2 c + wn
-    w1, b1, w2 = h16("ff1.w"), w["ff1.b"].numpy(), h16("ff2.w")
+    w1, b1, w2 = fw("ff1.w", "norm3"), (w["ff1.b"] + w["ff1.w"] @ w["norm3.b"]).numpy(), h16("ff2.w")
     for c in (0, 7, 19):
         t0 = 30 + 6 * c
         val = np.zeros((2, 32, C), np.float16)
@@ -98,9 +101,11 @@ def test_weight_stream_is_what_the_kernel_reads():
                         got[32 * j + lq, 16 * (2 * i + ksl) + 8 * hi:][:8] = frag[lane]
         assert np.array_equal(got, w2[:, 64 * c:64 * c + 64])
     prm = blk.tail_prm.numpy()
-    for row, n in enumerate(("out1.b", "norm2.w", "norm2.b", "out2.b", "norm3.w", "norm3.b", "ff2.b", "proj_out.b")):
-        assert np.array_equal(prm[row], w[n].numpy()), n
-    assert np.array_equal(blk.head_prm.numpy(), np.stack([w["proj_in.b"].numpy(), w["norm1.w"].numpy(), w["norm1.b"].numpy()]))
+    for row, exp in enumerate((w["out1.b"].numpy(), fb("q2.w", "norm2"), w["out2.b"].numpy(), w["ff2.b"].numpy(),
+                               w["proj_out.b"].numpy())):
+        assert np.array_equal(prm[row], exp), row
+    assert np.array_equal(blk.head_prm.numpy(), np.stack([w["proj_in.b"].numpy(), fb("q1.w", "norm1"), fb("k1.w", "norm1"),
+                                                          fb("v1.w", "norm1")]))
 
 
 def _xoff(rowblk, kst, col, lq):  # xformer.hip: xoff()

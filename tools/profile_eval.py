@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--pair", action="store_true", help="the CFG evaluation the samplers issue: [uncond || cond] with cfg_pair")
     ap.add_argument("--pmc-mode", action="store_true", help="under rocprofv3 --pmc: 1 warm + 1 evaluation, no tables")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -27,6 +28,10 @@ def main():
     B2 = 2 * a.batch
     x = torch.randn(B2, 4, 64, 64, device=dev)
     cond = dict(c_txt=torch.randn(B2, 77, 1024, device=dev), c_img=torch.randn(B2, 4, 64, 64, device=dev))
+    if a.pair:
+        x = torch.randn(a.batch, 4, 64, 64, device=dev).repeat(2, 1, 1, 1)
+        cond["c_img"] = torch.randn(a.batch, 4, 64, 64, device=dev).repeat(2, 1, 1, 1)
+        cond["cfg_pair"] = (1, a.batch)
     t = torch.full((B2,), 500.0, device=dev)
     for _ in range(1 if a.pmc_mode else 2):
         cldm(x, t, cond)
