@@ -9,7 +9,8 @@ seeded inputs, random-init weights of the real architecture (no checkpoints / da
 Other BASELINE configs (each prints its own JSON line with its own roofline record):
   --config c3   BFR, DPM-Solver++(2M) 20 steps + CFG, fp16, batch 4 per GPU (32 over 8 GPUs), data-parallel
   --config c4   tiled sampling, 1x2048x2048, tile 512 / stride 256, 50 spaced steps; N > 1: tiles sharded (all-reduce)
-  --config c5   tiled sampling, 4096x4096, bf16, tiles sharded over the N GPUs (strong scaling: one image per step)
+  --config c5   tiled sampling, 4 x 4096x4096, bf16 (BASELINE configs[4]): images over gcd(4, N) GPU groups, tiles
+                sharded over the N / gcd ranks of a group (strong scaling: the same 4 images per step at every N)
 
 N GPUs: one process per GPU over RCCL.  The driver launches `python -m torch.distributed.run --nproc-per-node N ...
 bench.py --gpus N`; `python bench.py --gpus N` alone re-launches itself that way, and a WORLD_SIZE that disagrees with
@@ -48,9 +49,9 @@ CONFIGS = {
     "c4": dict(batch=1, size=2048, sampler="spaced", sampler_steps=50, dtype="fp16", tiled=True, scaling="strong",
                desc="tiled sampling (mixture of diffusers), {b}x2048x2048, tile 512 / stride 256, {s}-step SpacedSampler "
                     "+ CFG=4.0, {d}, tiles sharded over the GPUs"),
-    "c5": dict(batch=1, size=4096, sampler="spaced", sampler_steps=50, dtype="bf16", tiled=True, scaling="strong",
-               desc="tiled sampling, {b}x4096x4096, tile 512 / stride 256, {s}-step SpacedSampler + CFG=4.0, {d}, tiles "
-                    "sharded over the GPUs"),
+    "c5": dict(batch=4, size=4096, sampler="spaced", sampler_steps=50, dtype="bf16", tiled=True, scaling="strong",
+               desc="tiled sampling, {b}x4096x4096, tile 512 / stride 256, {s}-step SpacedSampler + CFG=4.0, {d}, images "
+                    "over GPU groups x tiles sharded within a group (parallel.hybrid_split)"),
 }
 
 
@@ -292,6 +293,8 @@ def main():
             assert all(torch.equal(v, lo_hi[0]) for v in lo_hi), "broadcast_state_dict: ranks disagree"
             extra["broadcast_checked"] = True
 
+        split = None
+
         def run_step():
             time.sleep(0.02 * (1 + rank))  # ranks differ: the reported time must be the slowest rank's
             return np.full((args.batch, 64, 64, 3), rank, dtype=np.uint8)
@@ -305,11 +308,22 @@ def main():
         pipe, cldm, swin = build_engine(device, dtype, ctx)
         if world > 1:
             extra["weights"] = "generated on rank 0, shipped by parallel.broadcast_state_dict (RCCL, 256 MB buckets)"
+            extra["rccl"] = dict(ranks=dist.get_world_size(), backend=dist.get_backend(),
+                                 version=".".join(str(v) for v in torch.cuda.nccl.version()))
         rs = np.random.RandomState(100 + (0 if cfg["tiled"] else rank))
         lq = rs.randint(0, 256, (args.batch, cfg["size"], cfg["size"], 3)).astype(np.uint8)
         lq_dev = torch.as_tensor(lq).to(device)          # inputs resident in HBM before the timed region
+        split = None
         if cfg["tiled"]:
-            parallel.enable_tile_sharding(pipe, ctx, seed=231)   # same noise on every rank, tiles rank::world
+            # images over rank groups, tiles rank-in-group::group-size (batch 1: one group = plain tile sharding);
+            # full-batch noise from ONE seed on every rank, each group keeps its images' rows
+            split = parallel.hybrid_split(ctx, args.batch)
+            sub, lo, hi = split
+            noise = parallel.ShardedNoise.seeded(231, device)
+            pipe.randn = parallel.ShardedNoise(noise, args.batch, lo, hi) if hi - lo != args.batch else noise
+            parallel.enable_tile_sharding(pipe, sub, seed=None)
+            lq_dev = lq_dev[lo:hi].contiguous()
+            extra["hybrid"] = dict(groups=world // sub.world, ranks_per_group=sub.world, images_per_group=hi - lo)
         else:
             torch.manual_seed(231 + rank)
 
@@ -337,8 +351,13 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert out.dtype == np.uint8 and out.shape[0] == args.batch
+    assert out.dtype == np.uint8 and out.shape[0] == (args.batch if split is None else split[2] - split[1])
     sharded_batch = not cfg["tiled"]
+    if world > 1 and not sharded_batch and not args.selftest:   # group leaders' images -> rank 0 (outside the timed region)
+        full = parallel.gather_group_outputs(out, args.batch, ctx, split[0])
+        if rank == 0:
+            assert full.shape[0] == args.batch, full.shape
+            extra["gathered_batch"] = list(full.shape)
     if world > 1 and sharded_batch:   # outside the timed region: the restored slices travel to rank 0 over RCCL
         full = parallel.gather_batch(out, args.batch * world, ctx)
         if rank == 0:

@@ -221,6 +221,9 @@ class _EvalGraph:
         # warm-up outside the capture: packs weights, fills the context K/V cache, sizes split-K workspaces
         cldm._forward_eager(self.x, self.t, cond)
         torch.cuda.synchronize(dev)
+        # the captured kernels read the cached cross-attention K / V^T of this context through raw pointers: own them
+        # (the networks' caches are bounded and may drop the entry while this graph is still replayed)
+        self.ctx_kv = (cldm.unet.context_kv(c_txt), cldm.controlnet.context_kv(c_txt))
         if cldm._graph_pool is None:
             cldm._graph_pool = torch.cuda.graph_pool_handle()
         self.graph = torch.cuda.CUDAGraph()

@@ -17,7 +17,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import native, tuning
+from . import autotune, native, tuning
 from .native import (ACT_GEGLU, ACT_GELU, ACT_LRELU, ACT_NONE, ACT_SILU, MODE_CONV3X3, MODE_LINEAR,  # noqa: F401
                      GemmDesc)
 
@@ -173,6 +173,9 @@ class _Timed:
 
 _TUNER = None  # tools/autotune.py installs an object with .run(d, out) while measuring tile variants
 _WS = {}       # device -> f32 split-K workspace (grown on demand, reused by every launch on that device's stream)
+_WS_KEEP = []  # superseded workspaces: captured HIP graphs (model/cldm.py) hold raw pointers into them, so a regrown
+               # workspace must never be returned to the allocator while the process lives (a few hundred MB at most:
+               # sizes at least double)
 
 
 def splitk_workspace(device, nbytes: int) -> T:
@@ -180,6 +183,9 @@ def splitk_workspace(device, nbytes: int) -> T:
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _WS_KEEP.append(ws)
+            nbytes = max(nbytes, 2 * ws.numel() * 4)
         ws = torch.empty(max(nbytes, 64 << 20) // 4, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
@@ -199,7 +205,17 @@ def _gemm_launch(d: GemmDesc, keep):
     out = keep[2]
     from_table = False
     if d.tile == 0:
-        code = _TUNER.run(d, out) if _TUNER is not None else tuning.lookup(d)
+        if _TUNER is not None:
+            code = _TUNER.run(d, out)
+        else:
+            code = tuning.lookup_exact(d)
+            if code is None:   # not in the shipped table: this device's first-use autotune cache, tuned on a miss
+                key = tuning.key_of(d)
+                code = autotune.lookup(key)
+                if code is None:
+                    code = autotune.tune(d, out, apply_tile_code)
+                if code is None:
+                    code = tuning.lookup(d)   # nearest-M entry of the problem class, then the C heuristic
         from_table = code != 0
         apply_tile_code(d, code, out.device)
     tag = ""

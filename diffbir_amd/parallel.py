@@ -12,6 +12,8 @@ shards naturally because every stage is per-sample (GroupNorm / LayerNorm are pe
     on one generator (pipeline.py:159, spaced_sampler.py:181).  `ShardedNoise` makes every rank draw the full-batch
     tensor from an identically seeded generator, in the same order, and keep its rows — the restored images do not
     depend on the number of GPUs (64 KB per sample per step: cheaper than a broadcast).
+  * **hybrid** (`hybrid_split` / `run_hybrid`): several large images on more GPUs than images — images over rank groups,
+    tiles over the ranks of a group (one all-reduce per evaluation inside the group only).
   * **tile sharding** (`enable_tile_sharding`) for tiled sampling of large images: the T tiles of one network
     evaluation are split round-robin over the ranks and the partial weighted sums are combined with ONE all-reduce
     per evaluation (`diffbir_amd.utils.tiling.TiledModel`); every rank then performs the (cheap, deterministic given
@@ -195,6 +197,68 @@ def enable_tile_sharding(pipe, ctx: DistContext, seed: Optional[int] = 231, chec
         pipe.tile_all_reduce = reduce
     if seed is not None and getattr(pipe, "randn", None) is None:
         pipe.randn = ShardedNoise.seeded(seed, ctx.device)
+
+
+def hybrid_split(ctx: DistContext, n_images: int) -> Tuple[DistContext, int, int]:
+    """Images over rank GROUPS x tiles within a group (BASELINE config C5 = 4 images of 4096x4096 on 8 GPUs
+    -> 4 groups of 2 ranks; each group restores one image with its tiles sharded over the group's ranks).
+
+    G = gcd(n_images, world) groups of S = world / G consecutive ranks (neighbours on the xGMI ring); group g owns the
+    images [g * n_images / G, (g + 1) * n_images / G).  Returns (sub-context of this rank's group: rank / world / process
+    group for `enable_tile_sharding`, first image, one-past-last image).  Every rank must call this (it creates the
+    sub-groups collectively).  world == 1 or G == world (one rank per group) need no sub-groups."""
+    import math
+    G = math.gcd(max(n_images, 1), ctx.world)
+    S = ctx.world // G
+    g, r = ctx.rank // S, ctx.rank % S
+    per = n_images // G
+    group = None
+    if ctx.world > 1 and S > 1:
+        for gi in range(G):   # new_group is collective: every rank creates every group, keeps its own
+            h = dist.new_group(list(range(gi * S, (gi + 1) * S)))
+            if gi == g:
+                group = h
+    return DistContext(r, S, ctx.device, group), g * per, (g + 1) * per
+
+
+def gather_group_outputs(local: Optional[np.ndarray], n_images: int, ctx: DistContext, sub: DistContext,
+                         dst: int = 0) -> Optional[np.ndarray]:
+    """After a hybrid run every rank of a group holds the group's restored images: the group leaders' slices -> rank
+    `dst` in image order (RCCL gather over the WORLD group; the other ranks of a group contribute nothing)."""
+    if ctx.world == 1:
+        return local
+    G = ctx.world // sub.world
+    per = n_images // G
+    t = torch.as_tensor(local).to(ctx.device).contiguous()
+    bufs = [torch.empty_like(t) for _ in range(ctx.world)] if ctx.rank == dst else None
+    dist.gather(t, bufs, dst=dst, group=ctx.group)
+    if ctx.rank != dst:
+        return None
+    return np.concatenate([bufs[gi * sub.world][:per].cpu().numpy() for gi in range(G)], axis=0)
+
+
+def run_hybrid(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise: Optional[Callable] = None,
+               gather: bool = True, split=None):
+    """Tiled restoration of a batch of large images on `ctx.world` GPUs: images over groups, tiles within a group.
+    `noise`: full-batch noise source shared by ALL ranks (identically seeded; default: device generator, seed 231) — every
+    group draws the full-batch tensors and keeps its images' rows, so the result does not depend on the GPU count.
+    `split`: the (sub, lo, hi) of an earlier `hybrid_split` (sub-groups are created once)."""
+    B = lq.shape[0]
+    sub, lo, hi = split if split is not None else hybrid_split(ctx, B)
+    if noise is None:
+        if getattr(ctx, "_noise", None) is None:
+            ctx._noise = ShardedNoise.seeded(231, ctx.device)
+        noise = ctx._noise
+    prev = pipe.randn
+    pipe.randn = ShardedNoise(noise, B, lo, hi) if hi - lo != B else noise
+    enable_tile_sharding(pipe, sub, seed=None)
+    try:
+        out = pipe.run(lq[lo:hi], *run_args)
+    finally:
+        pipe.randn = prev
+    if not gather:
+        return out
+    return gather_group_outputs(out, B, ctx, sub)
 
 
 def run_data_parallel(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise: Optional[Callable] = None,

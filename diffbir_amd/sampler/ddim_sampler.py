@@ -78,7 +78,9 @@ class DDIMSampler(Sampler):
             ti = total - i - 1
             model_t = torch.full((bs,), int(step), device=device, dtype=torch.float32)
             s = float(self.get_cfg_scale(cfg_scale, int(step)))
-            if use_cfg:   # the reference mixes whenever uncond is given and cfg_scale != 1 (also when s happens to be 1)
+            if use_cfg:   # decided once from the caller's cfg_scale; the reference decides per step from the rescaled
+                          # scale (ddim_sampler.py:150-160) — identical results: where that scale is exactly 1 the
+                          # unconditional term below is multiplied by 0
                 o = fwd(torch.cat([x, x], dim=0), torch.cat([model_t, model_t]), cond2)
                 ou, oc = o[:bs].contiguous(), o[bs:].contiguous()
             else:

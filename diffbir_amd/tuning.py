@@ -40,11 +40,28 @@ def load(path: Optional[str] = None) -> Dict[str, int]:
         for k, v in raw.get("tiles", raw).items():
             tab[k] = int(v["tile"] if isinstance(v, dict) else v)
     _table = tab
+    _ensure_classes(tab)
+    return tab
+
+
+_classes_of = None  # the table object `_classes` was built from (tests / tools may install their own `_table`)
+
+
+def _ensure_classes(tab) -> None:
+    global _classes_of
+    if _classes_of is tab:
+        return
     _classes.clear()
     for k, t in tab.items():
         parts = k.split(":")
         _classes.setdefault(":".join(parts[:1] + parts[2:]), []).append((int(parts[1]), t))
-    return tab
+    _classes_of = tab
+
+
+def lookup_exact(d) -> Optional[int]:
+    """The shipped table's entry for exactly this problem key, or None."""
+    tab = _table if _table is not None else load()
+    return tab.get(key_of(d))
 
 
 def lookup(d) -> int:
@@ -53,10 +70,14 @@ def lookup(d) -> int:
     hit = tab.get(key)
     if hit is not None:
         return hit
+    _ensure_classes(tab)
     parts = key.split(":")
     best, best_r = 0, 2.0 + 1e-9
     for m, t in _classes.get(":".join(parts[:1] + parts[2:]), ()):
         r = max(m, d.M) / max(min(m, d.M), 1)
         if r <= best_r and t:
             best, best_r = t, r
-    return best
+    # a borrowed entry keeps its tile shape but NOT its split-K factor: the slice count was measured for another M (the
+    # workspace it implies scales with M, and captured HIP graphs hold pointers into the workspace); dbir_gemm still
+    # refuses tiles the shape cannot run and the launch falls back to the C heuristic
+    return best % 100

@@ -5,8 +5,9 @@ same names, types, defaults and choices), driving the same loop classes (`diffbi
     python inference.py --task sr --upscale 4 --version v2.1 --sampler spaced --steps 50 --captioner none \
         --cfg_scale 4 --input inputs/demo/bsr --output results/demo_bsr --precision fp16 --device cuda
 
-Checkpoints are looked up under ./weights/<file name of the reference's download URL>.  Tasks whose stage-1 model is
-not SwinIR (`denoise`: SCUNet, `unaligned_face`: RetinaFace + SwinIR, `--version custom`) are outside this engine.
+Checkpoints are looked up under ./weights/<file name of the reference's download URL>.  `--task sr | face | denoise`
+and `--version v1 | v2 | v2.1 | custom` run on the engine (SwinIR / BSRNet / SCUNet stage-1 models); `unaligned_face`
+(RetinaFace detection) and the LLaVA / RAM captioners are outside it and raise with a pointer to DESIGN.md §7.
 """
 from argparse import ArgumentParser, Namespace
 

@@ -73,3 +73,35 @@ def test_tuning_table_is_wellformed():
     for k, v in raw.items():
         tile, sk = int(v["tile"]) % 100, int(v["tile"]) // 100
         assert 0 <= tile <= 73 and 0 <= sk <= 16, (k, v["tile"])   # tiles 0..73 exist in gemm*.hip
+
+
+def test_first_use_autotune_candidates_and_cache(tmp_path, monkeypatch):
+    """Table misses are tuned on first use (diffbir_amd/autotune.py): candidate list = the problem class's winners in the
+    shipped table + a short generic list; results persist in a per-device cache file; split-K codes are never borrowed by
+    the nearest-M fallback."""
+    import json
+    from diffbir_amd import autotune, tuning
+    tab = tuning.load(tuning.DEFAULT_PATH)
+    key = next(k for k, v in tab.items() if v and v < 100)
+    cls_winners = {v for k, v in tab.items() if autotune.class_of(k) == autotune.class_of(key) and v}
+    cands = autotune.candidates(key)
+    assert 0 < len(cands) <= 24 and len(set(cands)) == len(cands)
+    assert set(cands[: len(cls_winners)]) <= cls_winners | set(autotune.ALWAYS)
+    assert autotune.candidates("0:12345:7:9:a0:s0:u0:z1:r0:v0")[:3] == autotune.GENERIC[:3]
+    monkeypatch.setenv("DBIR_AUTOTUNE_CACHE", str(tmp_path))
+    monkeypatch.setattr(autotune, "_cache", None)
+    monkeypatch.setattr(autotune, "ENABLED", True)
+    assert autotune.lookup("some:key") is None
+    autotune._load()["some:key"] = 37
+    monkeypatch.setattr(autotune, "_dirty", True)
+    autotune.save()
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1 and json.load(open(files[0]))["tiles"] == {"some:key": 37}
+    monkeypatch.setattr(autotune, "_cache", None)
+    assert autotune.lookup("some:key") == 37
+
+    class D:   # a key that is not in the table: the nearest-M fallback keeps the tile but drops the split-K factor
+        mode, N, K, act, stride, upsample, batch, R, rowvec, store_mode, out_f32 = 1, 1280, 11520, 0, 1, 0, 1, 1, None, 0, 0
+    d = D()
+    d.M = 4096 + 8
+    assert tuning.lookup_exact(d) is None and 0 <= tuning.lookup(d) < 100

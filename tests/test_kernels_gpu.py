@@ -665,6 +665,43 @@ def test_xf_head(B, L, dtype):
     check("groupnorm_affine == groupnorm", aff, gn, dtype)
 
 
+def test_xf_fp16_range_stress():
+    """SD-like activation statistics in fp16: a residual stream with a few outlier channels of
+    magnitude ~3e3 (LayerNorm statistics dominated by them: two-pass variance), GEGLU pre-activations of O(1e2) whose
+    products reach ~1e4 (fp16 max 65504), attention logits of O(1e2).  The fused kernels must stay finite and agree with
+    the f32 statement rounded at the same points; the per-launch kernels are held to the same inputs."""
+    dtype, C, heads, Lk, B, L = torch.float16, 320, 5, 77, 2, 512
+    w = _xf_weights(seed=7, gain=2.5)
+    w["ff1.b"] = w["ff1.b"] * 20
+    blk = ops.pack_xf_block(w, dtype, DEV)
+    g = torch.Generator().manual_seed(11)
+    h = torch.randn(B * L, C, generator=g) * 2.0
+    h[:, [7, 93, 200, 311]] += torch.tensor([3000.0, -2500.0, 1800.0, -3200.0])       # outlier channels
+    attn = torch.randn(B * L, C, generator=g) * 20.0
+    x = torch.randn(B, L // 64, 64, C, generator=g) * 30.0
+    k, vt = torch.randn(B, Lk, C, generator=g) * 3.0, torch.randn(B, C, 80, generator=g) * 10.0
+    h, attn, x, k, vt = (t.to(DEV).to(dtype) for t in (h, attn, x, k, vt))
+    kf, vf = ops.pack_context_frags(k, vt, Lk, heads)
+    ek, ev = emu.pack_context_frags(k, vt, Lk, heads)
+    for code, name in XF_STOPS:
+        got = ops.xf_tail(attn, h, x, blk, kf, vf, Lk, 0.125, L, stop_after=code)
+        ref = emu.xf_tail(attn, h, x, blk, ek, ev, Lk, 0.125, L, stop_after=code)
+        assert torch.isfinite(ref.float()).all(), f"stress inputs overflow the f32 statement itself at {name}"
+        check(f"xf_tail stress {name} (|ref| max {ref.float().abs().max().item():.0f})", got, ref, dtype, scale=3.0)
+    # the same block through the per-launch kernels (GEGLU epilogue, LayerNorm, cross-attention kernels)
+    n3 = emu.xf_tail(attn, h, x, blk, ek, ev, Lk, 0.125, L, stop_after=4)
+    pw1 = ops.pack_geglu(w["ff1.w"], w["ff1.b"], dtype, DEV)
+    n3a = emu._ln(emu.xf_tail(attn, h, x, blk, ek, ev, Lk, 0.125, L, stop_after=14).float(), w["norm3.w"].to(DEV),
+                  w["norm3.b"].to(DEV)).to(dtype)
+    gg = ops.linear(n3a, pw1)
+    u = n3a.float() @ w["ff1.w"].to(DEV).to(dtype).float().t() + w["ff1.b"].to(DEV)
+    ref_g = (u[:, : 4 * C] * torch.nn.functional.gelu(u[:, 4 * C:])).to(dtype)
+    assert torch.isfinite(ref_g.float()).all() and ref_g.float().abs().max() > 2e3 and n3.shape == n3a.shape
+    check(f"GEGLU epilogue stress (|ref| max {ref_g.float().abs().max().item():.0f})", gg, ref_g, dtype, scale=2.0)
+    ln = ops.layernorm(emu.xf_tail(attn, h, x, blk, ek, ev, Lk, 0.125, L, stop_after=14), w["norm3.w"].to(DEV), w["norm3.b"].to(DEV))
+    check("LayerNorm with outlier channels", ln, n3a, dtype, scale=2.0)
+
+
 def test_xf_rejects_unsupported():
     dtype = torch.float16
     blk = ops.pack_xf_block(_xf_weights(), dtype, DEV)

@@ -125,3 +125,20 @@ def test_cleaners_match_reference_golden(golden_dir, name):
     cfg, W, x = cases.cleaner_case(name)
     fn = nets.rrdbnet_forward if name.startswith("bsrnet") else nets.scunet_forward
     _close(fn(W, cfg, x), g[name], 2e-5)
+
+
+def test_golden_manifest(golden_dir):
+    """Every fixture under tests/golden/ is listed in MANIFEST.json with its sha256 (tools/golden_manifest.py): a fixture
+    cannot change silently, and each entry records the generator sources (oracle/make_golden.py, oracle/cases.py, ...) it
+    was produced with."""
+    import hashlib
+    import json
+    with open(os.path.join(golden_dir, "MANIFEST.json")) as f:
+        man = json.load(f)
+    names = sorted(n for n in os.listdir(golden_dir) if n != "MANIFEST.json")
+    assert names == sorted(man["files"]), set(names) ^ set(man["files"])
+    for n in names:
+        h = hashlib.sha256(open(os.path.join(golden_dir, n), "rb").read()).hexdigest()
+        assert h == man["files"][n]["sha256"], f"{n} changed without `python tools/golden_manifest.py`"
+        g = man["files"][n]["generator"]
+        assert "note" in g or set(g) >= {"oracle/make_golden.py", "oracle/cases.py"}

@@ -117,3 +117,54 @@ def test_world2_gloo_matches_reference_golden(golden_dir):
             assert np.array_equal(v0[k], v1[k]), "ranks must hold the same tiled-VAE result after the all-reduce"
             err = np.linalg.norm(v0[k] - gv[gk]) / np.linalg.norm(gv[gk])
             assert err < 2e-4, (k, err)
+
+
+def _hybrid_worker(rank: int, world: int, port: int, outdir: str):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import cases
+    from tests import emu_ops
+    from tests.helpers import build_engine
+    emu_ops.install(_Patch())
+    ctx = parallel.init_distributed("gloo", torch.device("cpu"))
+    with torch.no_grad():
+        pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", torch.device("cpu"), torch.float32, raw_dtype=True)
+        split = parallel.hybrid_split(ctx, 2)
+        sub, lo, hi = split
+        assert (sub.world, sub.rank, lo, hi) == (2, rank % 2, rank // 2, rank // 2 + 1)
+        args = (2, 1.0, False, 512, 256, False, 256, False, 256, True, 512, 256, "", cases.NEG_PROMPT, 4.0, "noise",
+                "spaced", 0, False, 0, 0, 300, 1, 1, 1)
+        lq = cases.make_lq(9, 2, 600, 712)
+        local = parallel.run_hybrid(pipe, lq, ctx, args, noise=cases.NoiseStream(5), gather=False, split=split)
+        np.save(os.path.join(outdir, f"hy_{rank}.npy"), local)
+        assert pipe.tile_shard == (rank % 2, 2)
+        full = parallel.gather_group_outputs(local, 2, ctx, sub)
+        if rank == 0:
+            np.save(os.path.join(outdir, "hy_full.npy"), full)
+        else:
+            assert full is None
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_world4_hybrid_images_x_tiles(monkeypatch):
+    """BASELINE config C5's decomposition at world 4: 2 images x 2 tile shards.  Ranks of a group agree bit
+    for bit, and the gathered batch equals the single-process tiled batch-2 run given the same full-batch noise (the tile
+    blend's f32 summation order differs between 1 and 2 shards: tolerance, not bit-exactness)."""
+    from oracle import cases
+    from tests import emu_ops
+    from tests.helpers import build_engine, run_pipe
+    world, port = 4, _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_hybrid_worker, args=(world, port, outdir), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, f"hy_{r}.npy")) for r in range(4)]
+        full = np.load(os.path.join(outdir, "hy_full.npy"))
+    assert np.array_equal(parts[0], parts[1]) and np.array_equal(parts[2], parts[3])
+    assert full.shape[0] == 2 and np.array_equal(full[0:1], parts[0]) and np.array_equal(full[1:2], parts[2])
+    emu_ops.install(monkeypatch)
+    with torch.no_grad():
+        pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", torch.device("cpu"), torch.float32, raw_dtype=True)
+        single = run_pipe(pipe, cases.make_lq(9, 2, 600, 712), 2, "spaced", 5, tiled=True)
+    assert cases.psnr_u8(full, single) > 55.0

@@ -162,6 +162,11 @@ FULL_CONFIG_CASES = {
     "c2_spaced50_b2": ((21, 2, 512, 512), 50, "spaced", 231, {}),
     "c3_dpm20_b2": ((22, 2, 512, 512), 20, "dpm++_m2", 231, {}),
     "c4_tiled1024_spaced10": ((23, 1, 1024, 1024), 10, "spaced", 231, dict(tiled=True, tile=512, stride=256)),
+    # round 3: the BENCHMARKED shapes themselves — C2 at the bench's batch 8 (16 samples per evaluation: the tile table's
+    # batch-8 entries and the fused transformer kernels' two-panels-per-workgroup path), C4 at 2048x2048 / 49 tiles
+    # (32-sample chunks of the tiled scheduler)
+    "c2_spaced50_b8": ((24, 8, 512, 512), 50, "spaced", 231, {}),
+    "c4_tiled2048_spaced10": ((25, 1, 2048, 2048), 10, "spaced", 231, dict(tiled=True, tile=512, stride=256)),
 }
 
 
@@ -222,6 +227,55 @@ def test_batch_independence():
         pipe.randn = lambda shape: next(it)
         one = pipe.run(lq[i:i + 1], *args)
         assert cases.psnr_u8(one, both[i:i + 1]) > 55.0
+
+
+def test_full_config_batch_independence_and_fused_blocks(full_engine):
+    """Full network size: (1) images are independent units — batch 4 == 4 x batch 1 given the same per-sample noise,
+    although the batch sizes select different tiles from the tuning table and different panel counts per workgroup in the
+    fused transformer kernels; (2) the fused C = 320 transformer kernels (xf_head / xf_tail) against the 16-launch path
+    they replace on the whole pipeline."""
+    pipe, cldm, swin = full_engine
+    lq = cases.make_lq(41, 4, 512, 512)
+    full = cases.NoiseStream(13)
+    draws = []
+
+    def rec(shape):
+        t = full(shape)
+        draws.append(t)
+        return t
+    pipe.randn = rec
+    args = (6, 1.0, False, 512, 256, False, 256, False, 256, False, 512, 256, "", cases.NEG_PROMPT, 4.0, "noise",
+            "spaced", 0, False, 0, 0, 300, 1, 1, 1)
+    both = pipe.run(lq, *args)
+    psnrs = []
+    for i in (0, 3):
+        it = iter([d[i:i + 1] for d in draws])
+        pipe.randn = lambda shape: next(it)
+        one = pipe.run(lq[i:i + 1], *args)
+        psnrs.append(cases.psnr_u8(one, both[i:i + 1]))
+    REPORT["full_batch_independence_psnr"] = psnrs
+    assert min(psnrs) > 50.0, psnrs
+    # (2) same weights, fused blocks off: every transformer block of the 64x64 level through the per-launch kernels
+    layers = [a for net in (cldm.unet, cldm.controlnet) for a in net._attn_layers]
+    saved = [a.xf for a in layers]
+    assert sum(x is not None for x in saved) == 7, "the 5 + 2 C = 320 blocks of UNet + ControlNet run fused by default"
+    try:
+        for a in layers:
+            a.xf = None
+        for net in (cldm.unet, cldm.controlnet):
+            net._ctx_cache.clear()
+        it = iter(list(draws))
+        pipe.randn = lambda shape: next(it)
+        plain = pipe.run(lq, *args)
+    finally:
+        for a, x in zip(layers, saved):
+            a.xf = x
+        for net in (cldm.unet, cldm.controlnet):
+            net._ctx_cache.clear()
+        pipe.randn = None
+    p2 = cases.psnr_u8(plain, both)
+    REPORT["full_fused_vs_per_launch_psnr"] = p2
+    assert p2 > 50.0, p2
 
 
 def test_vae_attention_query_chunking_is_exact():
