@@ -69,8 +69,15 @@ def parse(argv=None):
                          "configs when N > 1 (its tiles are then sharded over the ranks like the diffusion tiles; untiled, "
                          "every rank would repeat the whole VAE), off otherwise (one MI355X holds the untiled VAE of a "
                          "4096x4096 image: exact query-chunked attention)")
+    ap.add_argument("--parity-out", default=None,
+                    help="GPU-count parity mode (tests/test_multigpu_gpu.py): --batch is the GLOBAL batch, sharded over the "
+                         "ranks by parallel.run_data_parallel / run_hybrid with full-batch noise from one seed, and rank 0 "
+                         "saves the gathered uint8 result to this .npy — it must not depend on N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic in this job: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over "
+                         "the same network evaluation in subprocesses (+ ~2 min); default: the committed pass of this batch")
     ap.add_argument("--selftest", action="store_true",
                     help="CPU / gloo dry run of the launch, barrier, broadcast, gather, max-over-ranks and JSON plumbing "
                          "with a fake workload (tests/test_bench_plumbing_cpu.py); never a measurement")
@@ -145,12 +152,16 @@ def build_engine(device, dtype, ctx=None):
     return SwinIRPipeline(swin, cldm, diff, None, str(device)), cldm, swin
 
 
+def run_args(sampler_steps, sampler="spaced", tiled=False, vae_tiled=False):
+    return (sampler_steps, 1.0, False, 512, 256, vae_tiled, 256, vae_tiled, 256, tiled, 512, 256, "", NEG, 4.0, "noise",
+            sampler, 0, False, 0, 0, 300, 1, 1, 1)
+
+
 def run_once(pipe, lq, sampler_steps, sampler="spaced", tiled=False, vae_tiled=False):
-    return pipe.run(lq, sampler_steps, 1.0, False, 512, 256, vae_tiled, 256, vae_tiled, 256, tiled, 512, 256, "", NEG, 4.0,
-                    "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
+    return pipe.run(lq, *run_args(sampler_steps, sampler, tiled, vae_tiled))
 
 
-def measure_roofline(cldm, device, batch):
+def measure_roofline(cldm, device, batch, pmc=False):
     """Per-launch HIP-event timing (events recorded on torch's current stream = the stream the kernels are launched
     on) of every implicit-GEMM launch of ONE batched network evaluation (ControlNet + UNet at batch 2B)."""
     import torch
@@ -186,22 +197,66 @@ def measure_roofline(cldm, device, batch):
                traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1], eval_batch=2 * batch,
                avg_launch_us=g[1] / g[2] * 1e6, flops_per_launch=g[0] / g[2],
                algorithmic_bytes_per_launch=g[3] / g[2])
-    # HBM bytes per GEMM launch from the rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/; FETCH_SIZE doubled
-    # per the gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE), collected on the same network evaluation
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
-        pmc = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(pmc) and batch == 8:
-            with open(pmc) as f:
+    # HBM bytes per GEMM launch from rocprofv3 PMC passes (tools/pmc_traffic.sh; FETCH_SIZE doubled per the gfx950
+    # correction in MI355X_MICROARCH.md, + WRITE_SIZE) on the same network evaluation: taken IN THIS JOB (two separate
+    # --pmc passes in subprocesses, `pmc=True`), else from the last committed pass of the same evaluation batch
+    if pmc:
+        import shutil
+        import tempfile
+        if shutil.which("rocprofv3"):
+            tmp = tempfile.mkdtemp(prefix="dbir_pmc_")
+            try:
+                subprocess.run(["sh", os.path.join(ROOT, "tools", "pmc_traffic.sh"), tmp, str(batch)], cwd=ROOT, check=True,
+                               timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                with open(os.path.join(tmp, "pmc_traffic.json")) as f:
+                    tr = json.load(f)
+                if tr.get("gemm_bytes_per_eval"):
+                    out["traffic"] = tr["gemm_bytes_per_eval"] / g[2]
+                    out["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two passes in this job "
+                                             f"(tools/pmc_traffic.sh, evaluation batch {2 * batch})")
+            except Exception as e:  # counters unavailable here: say so, never invent
+                out["traffic_source"] = f"PMC passes failed in this job ({type(e).__name__}); traffic not measured"
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+    if out["traffic"] is None:
+        pmc_file = os.path.join(ROOT, "profiles", f"r3_pmc_traffic_b{batch}.json")
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as f:
                 tr = json.load(f)
             if tr.get("gemm_bytes_per_eval"):
                 out["traffic"] = tr["gemm_bytes_per_eval"] / g[2]   # HBM bytes per logical GEMM launch
-            out["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-            break
+                out["traffic_source"] = (f"profiles/r3_pmc_traffic_b{batch}.json (rocprofv3 --pmc passes of the same "
+                                         "evaluation, recorded on another box)")
     if "attention" in tot:
         a = tot["attention"]
         out["attention_kernel"] = dict(achieved=a[0] / a[1] / 1e12, frac=a[0] / a[1] / MFMA_PEAK, launches=a[2],
                                        seconds_per_eval=a[1])
     return out
+
+
+def reference_cpu_baseline(cores):
+    """The UNMODIFIED reference (`/root/reference`, SwinIRPipeline.run, CPU fp32) on a bounded sample of the c2 workload,
+    timed in this run — only where the reference checkout exists (the build container; never the GPU box).  Two runs of
+    one 512x512 image with 1 and 2 spaced steps: fixed cost (SwinIR + VAE + CLIP) and per-step cost (2 network
+    evaluations under CFG) -> 50-step time."""
+    import numpy as np
+    import torch
+    from oracle import cases, make_golden, ref_import
+    R = ref_import.load_reference()
+    from diffbir_amd import configs
+    torch.set_num_threads(cores)
+    cldm, swin, diff, _ = make_golden.build_reference(R, "full", configs.get("DIFFUSION_V21"))
+    lq = cases.make_lq(3, 1, 512, 512)
+    ts = []
+    for steps in (1, 2):
+        t0 = time.time()
+        make_golden.run_pipeline(R, cldm, swin, diff, lq, steps, "spaced", 231)
+        ts.append(time.time() - t0)
+    per_step = max(ts[1] - ts[0], 1e-9)
+    t_img = ts[0] + 49 * per_step
+    return dict(value=1.0 / t_img, unit="images/sec", cores=cores, kind="reference",
+                sample=f"unmodified reference SwinIRPipeline.run, 1x512x512, CPU fp32, timed in this run: 1 step {ts[0]:.1f}s, "
+                       f"2 steps {ts[1]:.1f}s => {per_step:.1f}s per CFG step, {t_img:.0f}s per 50-step image")
 
 
 def cpu_baseline():
@@ -239,6 +294,17 @@ def cpu_baseline():
     out = dict(value=1.0 / t_img, unit="images/sec", cores=cores, kind="port",
                sample=f"1x512x512: SwinIR {t_swin:.1f}s + VAE-enc {t_enc:.1f}s + 1 of 50 CFG steps {t_step:.1f}s "
                       f"(x50 extrapolated) + VAE-dec {t_dec:.1f}s => {t_img:.0f}s/image")
+    try:   # the unmodified reference timed in the same run, wherever its checkout exists
+        from oracle import ref_import
+        if ref_import.have_reference():
+            out["reference_same_run"] = reference_cpu_baseline(cores)
+        else:
+            out["reference_same_run"] = None
+            out["reference_note"] = ("/root/reference does not exist on this host (the GPU box ships only the repo): the "
+                                     "unmodified reference cannot be timed here; `reference_recorded` is its wall time on "
+                                     "the build container, recorded when the golden vectors were generated")
+    except Exception as e:  # never let the baseline leg break the measurement line
+        out["reference_note"] = f"reference timing failed: {type(e).__name__}: {e}"
     gp = os.path.join(ROOT, "tests", "golden", "full_pipeline.npz")
     if os.path.exists(gp):
         g = np.load(gp)
@@ -333,6 +399,22 @@ def main():
         def run_step():
             return run_once(pipe, lq_dev, args.sampler_steps, cfg["sampler"], cfg["tiled"], vae_tiled)
 
+        if args.parity_out:   # one fixed global batch, sharded; result gathered on rank 0 and saved (not a measurement)
+            lq_all = np.random.RandomState(100).randint(0, 256, (args.batch, cfg["size"], cfg["size"], 3)).astype(np.uint8)
+            ra = run_args(args.sampler_steps, cfg["sampler"], cfg["tiled"], vae_tiled)
+            pipe.randn = None
+            if cfg["tiled"]:
+                full = parallel.run_hybrid(pipe, lq_all, ctx, ra, split=split)
+            else:
+                full = parallel.run_data_parallel(pipe, lq_all, ctx, ra)
+            if rank == 0:
+                np.save(args.parity_out, full)
+                print(json.dumps(dict(parity_out=args.parity_out, shape=list(full.shape), n_gpus=world, **extra)), flush=True)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
+
     def barrier():
         sync()
         if world > 1:
@@ -389,7 +471,7 @@ def main():
     if args.selftest:
         res["data"] = "SELFTEST (fake workload, CPU/gloo) - not a measurement"
     if rank == 0 and not args.no_roofline and not args.selftest:
-        res["roofline"] = measure_roofline(cldm, device, 16 if cfg["tiled"] else args.batch)
+        res["roofline"] = measure_roofline(cldm, device, 16 if cfg["tiled"] else args.batch, pmc=args.pmc)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.selftest:

@@ -306,8 +306,8 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 79 && tile != 13, "dbir_gemm: bad tile %d", tile);
-  if (tile >= 70) {
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 88 && tile != 13 && !(tile >= 74 && tile <= 79), "dbir_gemm: bad tile %d", tile);
+  if (tile >= 70 && tile < 80) {
     DBIR_CHECK_ARG(dbir_gemm_pers_eligible(d, tile),
                    "dbir_gemm: tile %d (persistent linear kernel) needs a dense linear with K %% 32 == 0, M a multiple of "
                    "the tile height, N %% 8 == 0, a 16-byte aligned 16-bit row-major output / residual and no row vector, "
@@ -320,7 +320,7 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
                    "operands and a 16-bit row-major output", tile);
     DBIR_CHECK_ARG(d.splitk <= 1 || ok, "dbir_gemm: split-K is implemented by the direct-to-LDS kernels only "
                    "(tiles >= 5, eligible operands)");
-    if (tile >= 50) {
+    if (tile >= 50 && tile < 70) {
       DBIR_CHECK_ARG(ok && d.store_mode == 0 && dbir_gemm_halo_eligible(d, tile),
                      "dbir_gemm: tile %d (halo-patch kernel) needs a stride-1 pad-1 3x3 convolution with Cin %% 64 == 0 "
                      "whose 256-row tiles are whole image rows", tile);

@@ -80,7 +80,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 //        read of tile k;  WAR: tile k+1 refills the slot of tile k-2, last read by group 1 two intervals earlier.
 // BKT = K depth of a tile (64, or 32: LDS rows of 64 B, 4 chunks; lets a 256x256 tile keep a 3-slot ring in 96 KB for
 // the de-phased schedule).
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE, int DEPH, int BKT>
+// XPF = 1 (needs PIPE = 1, lockstep): cross-tile fragment prefetch — the wait + barrier that acquires K tile kt + 1 sits
+// in front of the LAST k-step's MFMAs of tile kt (every fragment of tile kt is in registers by then), followed at once by
+// the first fragment reads of tile kt + 1 and the refill of tile kt's slot: the LDS latency and the barrier skew of a tile
+// boundary hide under MI x NJ armed MFMAs instead of standing between two tiles, and the ring runs one tile deeper (the
+// schedule measured on the fused transformer kernels, xformer.hip: 1300 -> 1100 cycles per 10-MFMA tile).
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE, int DEPH, int BKT, int XPF = 0>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses gfx950-only builtins (buffer descriptors, LDS-DMA, MFMA)
   constexpr int NT = 64 * WM * WN;
@@ -359,6 +364,51 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
     }
 #undef TSD
     if (grp == 0) asm volatile("s_barrier" ::: "memory");  // pairs group 1's extra barrier
+  } else if constexpr (XPF) {
+    static_assert(PIPE == 1 && (KS % 2) == 0, "cross-tile prefetch needs pipelined fragment reads and an even k-step count");
+    typename T::vec8 xf[2][MI], wf[2][NJ];
+    const char* base;
+#define LOAD_FRAGS_X(KS_, SET)                                                                                \
+  do {                                                                                                        \
+    const int co_ = ((2 * (KS_) + hi) ^ sw) * 16;                                                             \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) wf[SET][j] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * FSTR + co_);                           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) xf[SET][i] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * FSTR + co_);                           \
+  } while (0)
+// tile KT_ landed (this wave's share; up to STAGES - 2 later tiles stay in flight), every wave's share landed and every
+// wave has COMPLETED its reads of the previous tile (lgkmcnt(0)): that slot is refilled right behind the barrier
+#define ACQUIRE_X(KT_)                                                                                        \
+  do {                                                                                                        \
+    if ((KT_) + STAGES - 2 < nk) wait_vmcnt<(STAGES - 2) * LOADS>(); else wait_vmcnt<0>();                    \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
+    base = smem + c_slot * BUF_BYTES;                                                                         \
+    c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;                                                         \
+  } while (0)
+    ACQUIRE_X(0);
+    LOAD_FRAGS_X(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (STAGES - 1 < nk) STAGE();
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks < KS - 1) {
+          LOAD_FRAGS_X(ks + 1, (ks + 1) & 1);
+        } else if (kt + 1 < nk) {
+          ACQUIRE_X(kt + 1);
+          LOAD_FRAGS_X(0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kt + STAGES < nk) STAGE();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[ks & 1][j], xf[ks & 1][i], acc[i][j]);  // D[n][m]
+      }
+    }
+#undef LOAD_FRAGS_X
+#undef ACQUIRE_X
   } else {
   // DIAGNOSTIC (kDiag build, debug == 5): per-wave s_memtime accumulators {vmcnt wait, barrier wait, first reads +
   // stage issue, remaining reads + MFMA issue} -> workspace, read by tools/bench_one.py
@@ -509,7 +559,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
   }
 }
 
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0, int BKT = 64, int WPS = 0>
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0, int BKT = 64, int WPS = 0,
+          int XPF = 0>
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int RPP_ = 64 * WM * WN / (BKT / 8), BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
@@ -520,7 +571,7 @@ int launch2(G2Params& p, hipStream_t s) {
   constexpr int waves = WM * WN * (blocks_per_cu > 2 ? 2 : blocks_per_cu);
   // WPS > 0: explicit waves per SIMD (register budget 512 / WPS) for variants meant to run several blocks per CU
   constexpr int MINW = WPS > 0 ? WPS : (waves >= 8 ? 2 : 1);
-  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE, DEPH, BKT>;
+  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE, DEPH, BKT, XPF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -597,6 +648,16 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
     // epilogue (HBM-bound, GELU-heavy for GEGLU) overlaps another block's K loop without any in-kernel scheduling
     case 44: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 32, 4>(p, s);  // 256x128, 8 waves (64x64 each), 3-slot ring, 72 KB
     case 45: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 32, 3>(p, s);  // 128x128, 4 waves, 3-slot ring, 48 KB: 3 blocks / CU
+    // 80 - 88: lockstep tiles with cross-tile fragment prefetch (XPF = 1): 25 / 30 / 32 / 34 / 35 / 44 / 45 / 41 / 12-with-3-slots
+    case 80: return launch2<T, 2, 2, 2, 2, 2, 1, 0, 64, 0, 1>(p, s);   // 128x128, 4 waves, 2 slots
+    case 81: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 64, 0, 1>(p, s);   // 128x128, 4 waves, 3 slots
+    case 82: return launch2<T, 2, 4, 4, 2, 2, 1, 0, 64, 0, 1>(p, s);   // 256x256, 2 slots
+    case 83: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 64, 0, 1>(p, s);   // 256x128, 8 waves, 3 slots
+    case 84: return launch2<T, 8, 1, 1, 5, 2, 1, 0, 64, 0, 1>(p, s);   // 256x160, 8 waves, 2 slots
+    case 85: return launch2<T, 4, 1, 1, 5, 3, 1, 0, 64, 0, 1>(p, s);   // 128x160, 4 waves, 3 slots
+    case 86: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 32, 4, 1>(p, s);   // 256x128, K depth 32, 3 slots, 2 blocks / CU
+    case 87: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 32, 3, 1>(p, s);   // 128x128, K depth 32, 3 slots, 3 blocks / CU
+    case 88: return launch2<T, 2, 4, 4, 2, 4, 1, 0, 32, 0, 1>(p, s);   // 256x256, K depth 32, 4 slots
   }
   dbir_set_error("dbir_gemm: bad glds tile %d", tile);
   return DBIR_ERR_ARG;
@@ -689,7 +750,8 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
     else
       tile = 5;
   }
-  if (dd.act == DBIR_ACT_GEGLU && (tile == 14 || tile == 15 || tile == 16 || tile == 34 || tile == 35 || tile == 37 || tile == 38)) {
+  if (dd.act == DBIR_ACT_GEGLU && (tile == 14 || tile == 15 || tile == 16 || tile == 34 || tile == 35 || tile == 37 || tile == 38 ||
+                                   tile == 84 || tile == 85)) {
     dbir_set_error("dbir_gemm: GEGLU needs a tile whose waves hold value/gate column pairs (tiles 5-13)");
     return DBIR_ERR_ARG;
   }

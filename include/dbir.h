@@ -104,7 +104,12 @@ typedef struct dbir_gemm_desc {
                output tiles, the K tiles of all of them form one flat stream through the LDS ring, barrier-free
                register epilogue: 256x160 / 128x160 (two workgroups per CU) / 256x128 / 128x128 (two per CU); dense
                linear with K % 32 == 0, M a multiple of the tile height, N % 8 == 0, no row vector / split-K /
-               transposed or f32 store */
+               transposed or f32 store;
+               80 - 88: direct-to-LDS lockstep tiles with cross-tile fragment prefetch (the acquire of K tile kt + 1 sits
+               ahead of tile kt's last k-step): 128x128 (2 / 3 slots), 256x256, 256x128, 256x160, 128x160, then K depth 32:
+               256x128 (2 blocks / CU), 128x128 (3 blocks / CU), 256x256 (4 slots).
+               Ids 60 - 67 exist only in a DBIR_DIAG build (diagnostic ablations, meaningless outputs); 13 and 74 - 79
+               are invalid. */
   /* split-K (direct-to-LDS tiles >= 5 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
    * into f32 partial sums in `ws` (>= splitk * batch * M * N * 4 bytes, 16-byte aligned, caller-owned), then a second
    * kernel sums the slices in a fixed order and applies the epilogue.  For small-M / huge-K problems (8x8 and 16x16

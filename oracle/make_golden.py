@@ -210,6 +210,30 @@ def gen_full_configs(R, only=None):
 
 
 @torch.no_grad()
+def gen_full_bf16(R):
+    """BASELINE config C5's precision at FULL network size: one tiled case (768x768, tile 512 /
+    stride 256 = 4 tiles, 3 spaced steps + CFG) — the reference's fp32 output (the golden) and the PSNR of the reference's
+    OWN bf16 run (cast_dtype + autocast, what `--precision bf16` selects) against it: the yardstick the engine's bf16
+    result is held to (within 1.5 dB, tests/test_pipeline_gpu.py)."""
+    from diffbir_amd import configs
+    lq = cases.make_lq(26, 1, 768, 768)
+    kw = dict(tiled=True, tile=512, stride=256)
+    cldm, swin, diff, W = build_reference(R, "full", configs.get("DIFFUSION_V21"))
+    t0 = time.time()
+    ref = run_pipeline(R, cldm, swin, diff, lq, 3, "spaced", 231, **kw)
+    t_f32 = time.time() - t0
+    print("fp32", ref.shape, f"{t_f32:.1f} s", flush=True)
+    cldm.cast_dtype(torch.bfloat16)
+    t0 = time.time()
+    with torch.autocast("cpu", torch.bfloat16):
+        low = run_pipeline(R, cldm, swin, diff, lq, 3, "spaced", 231, **kw)
+    psnr = cases.psnr_u8(low, ref)
+    print("bf16", f"{time.time() - t0:.1f} s  PSNR vs fp32 {psnr:.2f} dB", flush=True)
+    np.savez_compressed(os.path.join(OUT, "full_c5_tiled768_spaced3_bf16.npz"), out=ref, ref_bf16_psnr=np.float64(psnr),
+                        ref_cpu_seconds=np.float64(t_f32), ref_cpu_threads=np.int64(torch.get_num_threads()))
+
+
+@torch.no_grad()
 def gen_tiled_vae(R):
     """Tiled VAE: the reference's VAEHook through ControlLDM.vae_encode / vae_decode with `tiled=True`
     (cldm.py:99-111,127-138) on the tiny config, edge tiles included, + its tile geometry for several sizes."""
@@ -464,3 +488,5 @@ if __name__ == "__main__":
         gen_cleaners(R)
     elif what == "full_configs":
         gen_full_configs(R, only=sys.argv[2:] or None)
+    elif what == "full_bf16":
+        gen_full_bf16(R)

@@ -39,12 +39,42 @@ def test_two_ranks_batch_sharded_over_rccl():
     r = _run(["--sampler-steps", "2", "--batch", "2"])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"
     assert r["gathered_batch"] == [4, 512, 512, 3] and "broadcast_state_dict" in r["weights"]
+    assert r["rccl"]["ranks"] == 2 and r["rccl"]["backend"] == "nccl"
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
 def test_two_ranks_tile_sharded_over_rccl():
     r = _run(["--config", "c4", "--sampler-steps", "2"])
     assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "tile-shard2" and r["scaling"] == "strong"
+
+
+def _parity(n, extra, out):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = ["bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--parity-out", out]
+    if n > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+               "127.0.0.1", "--master-port", str(_port())] + base + extra
+    else:
+        cmd = [sys.executable] + base + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import numpy as np
+    return np.load(out)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_gpu_count_parity_over_rccl(tmp_path):
+    """The restored images must not depend on the number of GPUs: batch sharding (full-batch noise from one seed, every
+    rank keeps its rows) is BIT-identical between 1 and 2 ranks; tile sharding changes the f32 summation order of the tile
+    blend (one RCCL all-reduce per evaluation) and must stay >= 55 dB from the 1-rank result."""
+    import numpy as np
+    a = _parity(1, ["--batch", "4", "--sampler-steps", "3"], str(tmp_path / "dp1.npy"))
+    b = _parity(2, ["--batch", "4", "--sampler-steps", "3"], str(tmp_path / "dp2.npy"))
+    assert a.shape == (4, 512, 512, 3) and np.array_equal(a, b), "batch-sharded output differs between 1 and 2 GPUs"
+    a = _parity(1, ["--config", "c4", "--sampler-steps", "2"], str(tmp_path / "t1.npy"))
+    b = _parity(2, ["--config", "c4", "--sampler-steps", "2"], str(tmp_path / "t2.npy"))
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    assert a.shape == b.shape and (mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 55.0)
 
 
 def test_gpus_flag_must_match_world_size():

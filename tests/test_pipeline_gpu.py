@@ -193,6 +193,25 @@ def test_full_baseline_configs_vs_reference_golden(golden_dir, full_engine, name
     assert min(per_image) >= 45.0, per_image
 
 
+def test_full_bf16_tiled_vs_reference_golden(golden_dir):
+    """BASELINE config C5's precision (bf16) at FULL network size on the tiled scheduler: 768x768, 4 tiles, 3 spaced steps.
+    The bar is the one stated for bf16 everywhere in this suite: within 1.5 dB of what the REFERENCE's own bf16 run reaches
+    against its fp32 output on the same case (recorded in the fixture by oracle/make_golden.py gen_full_bf16), floor 34 dB —
+    `north_star`'s 45 dB is an fp16 tolerance (8 vs 11 mantissa bits = 18 dB for any implementation)."""
+    path = os.path.join(golden_dir, "full_c5_tiled768_spaced3_bf16.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    g = np.load(path)
+    bar = max(34.0, float(g["ref_bf16_psnr"]) - 1.5)
+    dev = _dev()
+    pipe, cldm, swin = build_engine("full", "DIFFUSION_V21", dev, torch.bfloat16)
+    out = run_pipe(pipe, cases.make_lq(26, 1, 768, 768), 3, "spaced", 231, tiled=True, tile=512, stride=256)
+    psnr = cases.psnr_u8(out, g["out"])
+    REPORT["full_c5_tiled768_bf16"] = dict(psnr=psnr, reference_bf16_psnr=float(g["ref_bf16_psnr"]), bar=bar)
+    print(f"full bf16 tiled PSNR {psnr:.2f} dB (reference's own bf16: {float(g['ref_bf16_psnr']):.2f}, bar {bar:.2f})")
+    assert out.shape == g["out"].shape and psnr >= bar, (psnr, bar)
+
+
 def test_tiled_equals_untiled_when_single_tile():
     """size-independent property: with one tile covering the whole latent the tiled scheduler is the identity."""
     dev = _dev()

@@ -26,8 +26,8 @@ def read(outdir, counter):
 
 
 def family(name):
-    if "gemm_glds_kernel" in name or "gemm_ph_kernel" in name or "gemm_kernel" in name or "splitk_reduce" in name:
-        return "gemm"
+    if "gemm_" in name or "splitk_reduce" in name or "xf_head_kernel" in name or "xf_tail_kernel" in name:
+        return "gemm"   # the implicit-GEMM family incl. the fused transformer kernels (bench.py counts them in it)
     if "attn" in name:
         return "attention"
     if "gn_" in name or "ln_kernel" in name:
