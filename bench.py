@@ -385,10 +385,7 @@ def main():
             # full-batch noise from ONE seed on every rank, each group keeps its images' rows
             split = parallel.hybrid_split(ctx, args.batch)
             sub, lo, hi = split
-            noise = parallel.ShardedNoise.seeded(231, device)
-            pipe.randn = parallel.ShardedNoise(noise, args.batch, lo, hi) if hi - lo != args.batch else noise
             parallel.enable_tile_sharding(pipe, sub, seed=None)
-            lq_dev = lq_dev[lo:hi].contiguous()
             extra["hybrid"] = dict(groups=world // sub.world, ranks_per_group=sub.world, images_per_group=hi - lo)
         else:
             torch.manual_seed(231 + rank)
@@ -397,7 +394,13 @@ def main():
         extra["vae_tiled"] = vae_tiled
 
         def run_step():
-            return run_once(pipe, lq_dev, args.sampler_steps, cfg["sampler"], cfg["tiled"], vae_tiled)
+            if not cfg["tiled"]:
+                return run_once(pipe, lq_dev, args.sampler_steps, cfg["sampler"], False, vae_tiled)
+            outs = []   # a group's large images one at a time (parallel.run_hybrid), per-image noise seeded 231 + i
+            for i in range(split[1], split[2]):
+                pipe.randn = parallel.ShardedNoise.seeded(231 + i, device)
+                outs.append(run_once(pipe, lq_dev[i:i + 1], args.sampler_steps, cfg["sampler"], True, vae_tiled))
+            return np.concatenate(outs, axis=0)
 
         if args.parity_out:   # one fixed global batch, sharded; result gathered on rank 0 and saved (not a measurement)
             lq_all = np.random.RandomState(100).randint(0, 256, (args.batch, cfg["size"], cfg["size"], 3)).astype(np.uint8)

@@ -237,25 +237,27 @@ def gather_group_outputs(local: Optional[np.ndarray], n_images: int, ctx: DistCo
     return np.concatenate([bufs[gi * sub.world][:per].cpu().numpy() for gi in range(G)], axis=0)
 
 
-def run_hybrid(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise: Optional[Callable] = None,
+def run_hybrid(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise_for_image: Optional[Callable] = None,
                gather: bool = True, split=None):
-    """Tiled restoration of a batch of large images on `ctx.world` GPUs: images over groups, tiles within a group.
-    `noise`: full-batch noise source shared by ALL ranks (identically seeded; default: device generator, seed 231) — every
-    group draws the full-batch tensors and keeps its images' rows, so the result does not depend on the GPU count.
-    `split`: the (sub, lo, hi) of an earlier `hybrid_split` (sub-groups are created once)."""
+    """Tiled restoration of a batch of large images on `ctx.world` GPUs: images over groups, tiles within a group; a
+    group restores its images ONE AT A TIME (a 4096x4096 image alone takes ~25 GB of activations on one MI355X).
+    `noise_for_image(i)` -> the noise source (shape -> f32 tensor) of GLOBAL image i, identical on every rank: image i's
+    result depends neither on the GPU count nor on which group restores it.  Default: a device generator seeded
+    231 + i.  `split`: the (sub, lo, hi) of an earlier `hybrid_split` (sub-groups are created once)."""
     B = lq.shape[0]
     sub, lo, hi = split if split is not None else hybrid_split(ctx, B)
-    if noise is None:
-        if getattr(ctx, "_noise", None) is None:
-            ctx._noise = ShardedNoise.seeded(231, ctx.device)
-        noise = ctx._noise
+    if noise_for_image is None:
+        noise_for_image = lambda i: ShardedNoise.seeded(231 + i, ctx.device)  # noqa: E731
     prev = pipe.randn
-    pipe.randn = ShardedNoise(noise, B, lo, hi) if hi - lo != B else noise
     enable_tile_sharding(pipe, sub, seed=None)
+    outs = []
     try:
-        out = pipe.run(lq[lo:hi], *run_args)
+        for i in range(lo, hi):
+            pipe.randn = noise_for_image(i)
+            outs.append(pipe.run(lq[i:i + 1], *run_args))
     finally:
         pipe.randn = prev
+    out = np.concatenate(outs, axis=0) if outs else np.zeros((0,) + tuple(lq.shape[1:]), dtype=np.uint8)
     if not gather:
         return out
     return gather_group_outputs(out, B, ctx, sub)

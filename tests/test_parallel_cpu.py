@@ -136,7 +136,8 @@ def _hybrid_worker(rank: int, world: int, port: int, outdir: str):
         args = (2, 1.0, False, 512, 256, False, 256, False, 256, True, 512, 256, "", cases.NEG_PROMPT, 4.0, "noise",
                 "spaced", 0, False, 0, 0, 300, 1, 1, 1)
         lq = cases.make_lq(9, 2, 600, 712)
-        local = parallel.run_hybrid(pipe, lq, ctx, args, noise=cases.NoiseStream(5), gather=False, split=split)
+        local = parallel.run_hybrid(pipe, lq, ctx, args, noise_for_image=lambda i: cases.NoiseStream(5 + i), gather=False,
+                                    split=split)
         np.save(os.path.join(outdir, f"hy_{rank}.npy"), local)
         assert pipe.tile_shard == (rank % 2, 2)
         full = parallel.gather_group_outputs(local, 2, ctx, sub)
@@ -151,7 +152,7 @@ def _hybrid_worker(rank: int, world: int, port: int, outdir: str):
 @pytest.mark.slow
 def test_world4_hybrid_images_x_tiles(monkeypatch):
     """BASELINE config C5's decomposition at world 4: 2 images x 2 tile shards.  Ranks of a group agree bit
-    for bit, and the gathered batch equals the single-process tiled batch-2 run given the same full-batch noise (the tile
+    for bit, and the gathered batch equals the single-process image-by-image tiled run given the same per-image noise (the tile
     blend's f32 summation order differs between 1 and 2 shards: tolerance, not bit-exactness)."""
     from oracle import cases
     from tests import emu_ops
@@ -166,5 +167,6 @@ def test_world4_hybrid_images_x_tiles(monkeypatch):
     emu_ops.install(monkeypatch)
     with torch.no_grad():
         pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", torch.device("cpu"), torch.float32, raw_dtype=True)
-        single = run_pipe(pipe, cases.make_lq(9, 2, 600, 712), 2, "spaced", 5, tiled=True)
+        lq = cases.make_lq(9, 2, 600, 712)
+        single = np.concatenate([run_pipe(pipe, lq[i:i + 1], 2, "spaced", 5 + i, tiled=True) for i in range(2)], axis=0)
     assert cases.psnr_u8(full, single) > 55.0
