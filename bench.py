@@ -465,6 +465,8 @@ def main():
                    "global_batch": args.batch * (world if sharded_batch else 1), "sampler_steps": args.sampler_steps,
                    "parallelism": (f"dp{world}" if sharded_batch else f"tile-shard{world}")},
         "flops_per_image": fpi,
+        # REFERENCE-algorithmic FLOPs (two full batch-B evaluations per step) over wall time: with the shared CFG
+        # prefix the engine executes ~2 % fewer (the roofline record below counts executed FLOPs)
         "mfma_frac_end_to_end": value * fpi / (world * MFMA_PEAK),
         "vs_baseline_note": "BASELINE.json `published` is empty: the reference publishes no throughput numbers",
     }
