@@ -278,11 +278,28 @@ int dbir_gemm_halo(const dbir_gemm_desc& d, int tile, hipStream_t s);
 bool dbir_gemm_pers_eligible(const dbir_gemm_desc& d, int tile);
 int dbir_gemm_pers(const dbir_gemm_desc& d, int tile, hipStream_t s);
 
-extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
+// rows per tile for which the launch that just ran emits GroupNorm column sums (dbir_gemm_desc.stats); set by the
+// direct-to-LDS / halo launchers, 0 otherwise
+thread_local int g_dbir_stats_rows = 0;
+
+static int dbir_gemm_impl(const dbir_gemm_desc* dd, void* stream);
+
+extern "C" int dbir_gemm(dbir_gemm_desc* dd, void* stream) {
+  g_dbir_stats_rows = 0;
+  const int rc = dbir_gemm_impl(dd, stream);
+  if (dd) dd->stats_rows = rc == DBIR_OK ? g_dbir_stats_rows : 0;
+  return rc;
+}
+
+static int dbir_gemm_impl(const dbir_gemm_desc* dd, void* stream) {
   DBIR_CHECK_ARG(dd && dd->A && dd->W && dd->C, "dbir_gemm: null pointer");
   GemmParams p;
   p.d = *dd;
   dbir_gemm_desc& d = p.d;
+  // epilogue statistics: plain 16-bit row-major stores of the direct-to-LDS / halo kernels only
+  if (d.stats && (d.store_mode != 0 || d.out_f32 || d.act == DBIR_ACT_GEGLU || d.splitk > 1 || d.batch > 1 ||
+                  (reinterpret_cast<uintptr_t>(d.stats) & 15)))
+    d.stats = nullptr;
   DBIR_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "dbir_gemm: bad M/N/K %d %d %d", d.M, d.N, d.K);
   DBIR_CHECK_ARG(d.Kpad % BK == 0 && d.Kpad >= d.K, "dbir_gemm: Kpad %d must be a multiple of 64 and >= K %d",
                  d.Kpad, d.K);
@@ -312,6 +329,7 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
                    "dbir_gemm: tile %d (persistent linear kernel) needs a dense linear with K %% 32 == 0, M a multiple of "
                    "the tile height, N %% 8 == 0, a 16-byte aligned 16-bit row-major output / residual and no row vector, "
                    "split-K, transposed or f32 store", tile);
+    d.stats = nullptr;  // (the persistent kernel's register epilogue has no column-sum stage)
     return dbir_gemm_pers(d, tile, reinterpret_cast<hipStream_t>(stream));
   }
   if (tile == 0 || tile >= 5) {
@@ -329,6 +347,7 @@ extern "C" int dbir_gemm(const dbir_gemm_desc* dd, void* stream) {
     if (ok) return dbir_gemm_glds(d, p.Hv, p.Wv, tile, reinterpret_cast<hipStream_t>(stream));
   }
   DBIR_CHECK_ARG(d.splitk <= 1, "dbir_gemm: split-K needs the direct-to-LDS kernel (tile 5-12)");
+  d.stats = nullptr;  // generic register-staged kernel: no column-sum stage
   if (tile == 0) {
     // largest tile that still yields >= ~1.5 waves of blocks over the 256 CUs; GEGLU needs NJ == 2.
     const long long z = d.batch;

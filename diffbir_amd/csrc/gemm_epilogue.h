@@ -209,7 +209,75 @@ __device__ __forceinline__ void gemm_epilogue(const dbir_gemm_desc& d, const Epi
     }
     return;
   }
-  {
+  if (d.stats) {
+    // ---- store + GroupNorm column sums of the STORED values (host side: no GEGLU, M % BM == 0, one z slice) --------------
+    // a thread keeps ONE 8-column chunk and walks the tile's rows with stride RL, so its 8 sums / 8 sums of squares stay
+    // in registers; the RL row lanes are then combined through LDS in a fixed order (deterministic) and every column of
+    // the tile gets its two numbers: stats[tm][0][n] = sum, stats[tm][1][n] = sum of squares over the tile's BM rows.
+    constexpr int CPR = BN / 8, RL = NT / CPR;
+    const int ch = tid % CPR, rl = tid / CPR;
+    const int ncol = tn * BN + ch * 8;
+    const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) : nullptr;
+    u16* __restrict__ Cg = reinterpret_cast<u16*>(d.C);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    if (rl < RL && ncol < N) {
+      for (int row = rl; row < BM; row += RL) {
+        const int m = tm * BM + row;
+        float a[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(Cs + row * cs_ld + ch * 8), a);
+        if (ncol + 8 <= N) {
+          if (Rg) {
+            float b[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>(Rg + (long long)m * d.ldr + ncol), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += b[e];
+          }
+          const uint4 v = pack8<T>(a);
+          *reinterpret_cast<uint4*>(Cg + (long long)m * d.ldc + ncol) = v;
+          unpack8<T>(v, a);  // statistics of what was stored (16-bit rounded)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += a[e];
+            s2[e] += a[e] * a[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (ncol + e < N) {
+              float x = a[e];
+              if (Rg) x += T::to_f32(Rg[(long long)m * d.ldr + ncol + e]);
+              const u16 hv = T::from_f32(x);
+              Cg[(long long)m * d.ldc + ncol + e] = hv;
+              x = T::to_f32(hv);
+              s1[e] += x;
+              s2[e] += x * x;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // every read of the staged tile is done: reuse its LDS for the row-lane partials
+    float* ps = reinterpret_cast<float*>(smem);
+    if (rl < RL) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ps[(rl * CPR + ch) * 16 + e] = s1[e];
+        ps[(rl * CPR + ch) * 16 + 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    float* __restrict__ st = d.stats + (long long)tm * 2 * N;
+    for (int c = tid; c < 2 * BN; c += NT) {
+      const int which = c / BN, col = c - which * BN, n = tn * BN + col;
+      if (n < N) {
+        float a = 0.f;
+        for (int r = 0; r < RL; ++r) a += ps[(r * CPR + (col >> 3)) * 16 + which * 8 + (col & 7)];
+        st[which * N + n] = a;
+      }
+    }
+  } else {
     const int n_out = geglu ? N / 2 : N;
     const int ch_per_row = bn_out >> 3;
     const int total = BM * ch_per_row;

@@ -35,6 +35,8 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+extern thread_local int g_dbir_stats_rows;  // gemm.hip
+
 namespace {
 
 constexpr int BK = 64;
@@ -603,6 +605,10 @@ int launch2(G2Params& p, hipStream_t s) {
   }
   p.mtiles = cdiv(p.d.M, BM);
   p.ntiles = cdiv(p.d.N, BN);
+  if (p.d.stats) {  // GroupNorm column sums of the output from the epilogue: whole tiles only
+    if (p.splitk <= 1 && p.d.M % BM == 0) g_dbir_stats_rows = BM;
+    else p.d.stats = nullptr;
+  }
   const unsigned nz = p.d.batch > 0 ? p.d.batch : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles * p.splitk), nz);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);

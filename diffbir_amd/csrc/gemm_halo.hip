@@ -33,6 +33,8 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+extern thread_local int g_dbir_stats_rows;  // gemm.hip
+
 namespace {
 
 struct HParams {
@@ -490,6 +492,10 @@ static int launch_halo(HParams& p, hipStream_t s) {
   }
   p.mtiles = cdiv(dd.M, BM);
   p.ntiles = cdiv(dd.N, BN);
+  if (p.d.stats) {  // GroupNorm column sums of the output from the epilogue: whole tiles only
+    if (p.splitk <= 1 && dd.M % BM == 0 && !dd.out_f32) g_dbir_stats_rows = BM;
+    else p.d.stats = nullptr;
+  }
   auto kern = &gemm_halo_kernel<T, WM, WN, MI, NJ, PMAX, ABL, LS>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -148,7 +148,10 @@ class ControlLDM:
         return g.run(x_noisy, t, c_img)
 
     def reset_graphs(self):
+        """Drop every captured evaluation.  The shared private pool dies with its last graph, so the handle goes too
+        (capturing into a released pool trips an allocator assertion)."""
         self._graphs.clear()
+        self._graph_pool = None
 
     def _forward_eager(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
         """cond may carry the engine extension `cfg_pair` = (G, bs): the samplers set it on the [uncond || cond] batch

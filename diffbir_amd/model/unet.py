@@ -38,6 +38,9 @@ SHARE_CFG_PREFIX = os.environ.get("DBIR_SHARE_CFG_PREFIX", "1") != "0"
 # run the transformer blocks of the 64x64 level (C = 320) on the fused row-panel kernels (csrc/xformer.hip):
 # groupnorm_affine -> xf_head -> self-attention -> xf_tail instead of 16 launches (A/B switch: DBIR_FUSED_XF=0)
 FUSED_XF = os.environ.get("DBIR_FUSED_XF", "1") != "0"
+# GroupNorm statistics from the producing GEMM's epilogue (column sums per output tile, ops.GnPartials) instead of a
+# statistics pass over the tensor (A/B switch: DBIR_GN_EPILOGUE_STATS=0)
+GN_EPI_STATS = os.environ.get("DBIR_GN_EPILOGUE_STATS", "1") != "0"
 
 
 def _unique_of_pairs(t: T, pair: Tuple[int, int]) -> T:
@@ -167,7 +170,7 @@ class _DiffusionNet(NativeModule):
         t_host: the caller's promise that every element of `t` equals this host scalar (the samplers know their schedule):
         the rows are then computed once per (timestep, batch) and reused by every later step / pipeline pass."""
         key = None
-        if t_host is not None and not torch.cuda.is_current_stream_capturing():
+        if t_host is not None and not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
             key = (float(t_host), t.shape[0], str(self._dtype), str(t.device), self._gen)
             hit = self._temb_cache.get(key)
             if hit is not None:
@@ -183,12 +186,18 @@ class _DiffusionNet(NativeModule):
                 self._temb_cache.popitem(last=False)
         return out
 
-    def _res(self, r: _Res, x: T, emb_all: T, out: Optional[T] = None) -> T:
-        h = ops.groupnorm(x, r.gn1[0], r.gn1[1], 1e-5, True)
-        h = ops.conv3x3(h, r.conv1, rowvec=emb_all[:, r.emb_slice[0]:r.emb_slice[1]])
-        h = ops.groupnorm(h, r.gn2[0], r.gn2[1], 1e-5, True)
+    def _res(self, r: _Res, x: T, emb_all: T, out: Optional[T] = None, x_stats=None):
+        """-> (h, stats): `x_stats` / `stats` are the epilogue column sums (ops.GnPartials or None) of the block's input /
+        output, from which the next GroupNorm takes its statistics without reading the tensor."""
+        want = GN_EPI_STATS
+        h = ops.groupnorm(x, r.gn1[0], r.gn1[1], 1e-5, True, stats=x_stats)
+        h, st = ops.conv3x3(h, r.conv1, rowvec=emb_all[:, r.emb_slice[0]:r.emb_slice[1]], stats=want) if want else \
+            (ops.conv3x3(h, r.conv1, rowvec=emb_all[:, r.emb_slice[0]:r.emb_slice[1]]), None)
+        h = ops.groupnorm(h, r.gn2[0], r.gn2[1], 1e-5, True, stats=st)
         skip = x if r.skip is None else ops.linear(x, r.skip)
-        return ops.conv3x3(h, r.conv2, residual=skip, out=out)
+        if want:
+            return ops.conv3x3(h, r.conv2, residual=skip, out=out, stats=True)
+        return ops.conv3x3(h, r.conv2, residual=skip, out=out), None
 
     def context_kv(self, c_txt: T) -> list:
         """Cross-attention K and V^T of every transformer layer for a text context [B, 77, ctx_dim] (cached:
@@ -217,20 +226,21 @@ class _DiffusionNet(NativeModule):
         kv.append(c_txt)
         return kv
 
-    def _attn(self, a: _Attn, x: T, ctx_kv: list, out: Optional[T] = None, pair: Pair = None) -> T:
-        """pair: x holds the distinct samples of a CFG batch; the result is the full batch (see module docstring)."""
+    def _attn(self, a: _Attn, x: T, ctx_kv: list, out: Optional[T] = None, pair: Pair = None, x_stats=None):
+        """pair: x holds the distinct samples of a CFG batch; the result is the full batch (see module docstring).
+        -> (out, stats) as in `_res`."""
         B, H, W, C = x.shape
         L = H * W
         scale = self.plan.head_dim ** -0.5
         ckv = ctx_kv[a.ctx_idx]
         if a.xf is not None and len(ckv) == 4 and ops.xf_supported(C, L, ckv[0].shape[1]):
-            ab = ops.groupnorm_affine(x, a.gn[0], a.gn[1], 1e-6)
+            ab = ops.groupnorm_affine(x, a.gn[0], a.gn[1], 1e-6, stats=x_stats)
             h, qk, vt = ops.xf_head(x, ab, a.xf, L)
             o = torch.empty((B, L, C), dtype=x.dtype, device=x.device)
             ops.attention(qk[..., :C], qk[..., C:], vt, o, a.heads, L, scale)
             return ops.xf_tail(o, h, x, a.xf, ckv[2], ckv[3], ckv[0].shape[1], scale, L, out=out,
-                               pair_bs=pair[1] if pair is not None else 0)
-        hn = ops.groupnorm(x, a.gn[0], a.gn[1], 1e-6, False)
+                               pair_bs=pair[1] if pair is not None else 0), None
+        hn = ops.groupnorm(x, a.gn[0], a.gn[1], 1e-6, False, stats=x_stats)
         h = ops.linear(hn.reshape(B * L, C), a.proj_in)
         # self attention
         n = ops.layernorm(h, a.ln1[0], a.ln1[1])
@@ -257,14 +267,17 @@ class _DiffusionNet(NativeModule):
         h = ops.linear(g, a.ff2, residual=h)
         if out is None:
             out = torch.empty_like(x)
+        if GN_EPI_STATS:
+            return ops.linear(h, a.proj_out, residual=x, out=out, stats=True)
         ops.linear(h, a.proj_out, residual=x, out=out)
-        return out
+        return out, None
 
-    def _run_block(self, res: _Res, att: Optional[_Attn], h: T, emb_all: T, ctx_kv, out: Optional[T] = None) -> T:
+    def _run_block(self, res: _Res, att: Optional[_Attn], h: T, emb_all: T, ctx_kv, out: Optional[T] = None, x_stats=None):
+        """-> (h, stats of h)"""
         if att is None:
-            return self._res(res, h, emb_all, out=out)
-        h = self._res(res, h, emb_all)
-        return self._attn(att, h, ctx_kv, out=out)
+            return self._res(res, h, emb_all, out=out, x_stats=x_stats)
+        h, st = self._res(res, h, emb_all, x_stats=x_stats)
+        return self._attn(att, h, ctx_kv, out=out, x_stats=st)
 
     def _pair_ok(self, pair: Pair, batch: int) -> bool:
         """The shared CFG prefix applies when the encoder starts conv_in -> (ResBlock + transformer)."""
@@ -280,24 +293,27 @@ class _DiffusionNet(NativeModule):
         those of the full [G*2*bs] batch."""
         hs = []
         enc = self.enc
+        st = None   # epilogue column sums of the current h (GroupNorm statistics for its consumer), or None
         if pair is not None:
             h = ops.conv3x3(h, enc[0][1])
             hs.append(_expand_pairs(h, pair))
-            h = self._res(enc[1][1], h, _unique_of_pairs(emb_all, pair))
-            h = self._attn(enc[1][2], h, ctx_kv, pair=pair)
+            h, st = self._res(enc[1][1], h, _unique_of_pairs(emb_all, pair))
+            h, st = self._attn(enc[1][2], h, ctx_kv, pair=pair, x_stats=st)
             hs.append(h)
             enc = enc[2:]
         for blk in enc:
             if blk[0] == "conv_in":
-                h = ops.conv3x3(h, blk[1])
+                h, st = ops.conv3x3(h, blk[1]), None
             elif blk[0] == "res":
-                h = self._run_block(blk[1], blk[2], h, emb_all, ctx_kv)
+                h, st = self._run_block(blk[1], blk[2], h, emb_all, ctx_kv, x_stats=st)
+            elif GN_EPI_STATS:
+                h, st = ops.conv3x3(h, blk[1], stride=2, pad=1, stats=True)
             else:
-                h = ops.conv3x3(h, blk[1], stride=2, pad=1)
+                h, st = ops.conv3x3(h, blk[1], stride=2, pad=1), None
             hs.append(h)
-        h = self._res(self.mid[0], h, emb_all)
-        h = self._attn(self.mid[1], h, ctx_kv)
-        h = self._res(self.mid[2], h, emb_all)
+        h, st = self._res(self.mid[0], h, emb_all, x_stats=st)
+        h, st = self._attn(self.mid[1], h, ctx_kv, x_stats=st)
+        h, st = self._res(self.mid[2], h, emb_all, x_stats=st)
         return hs, h
 
 
@@ -347,16 +363,19 @@ class ControlledUnetModel(_DiffusionNet):
             cf = [(f, z, float(sc)) for f, z, sc in zip(*control_feats)]
         B = h.shape[0]
 
-        def add_control(skip: T, out: T) -> bool:
-            """out = skip + control (popping the next control / feature); False when there is no control."""
+        def add_control(skip: T, out: T):
+            """out = skip + control (popping the next control / feature) -> (done, epilogue column sums of `out` | None);
+            done = False when there is no control."""
             if control_feats is not None:
                 f, z, sc = cf.pop()
+                if GN_EPI_STATS:
+                    return True, ops.linear(f, z, out_scale=sc, residual=skip, out=out, stats=True)[1]
                 ops.linear(f, z, out_scale=sc, residual=skip, out=out)
-                return True
+                return True, None
             if control is not None:
                 ops.add_scaled(skip, control.pop(), 1.0, out=out)
-                return True
-            return False
+                return True, None
+            return False, None
 
         def cat_buf(blk, hh, ww):
             return torch.empty((B, hh, ww, blk["cin"]), dtype=self._dtype, device=h.device)
@@ -365,12 +384,14 @@ class ControlledUnetModel(_DiffusionNet):
         b0 = self.plan.output[0]
         buf = cat_buf(b0, h.shape[1], h.shape[2])
         left = buf[..., : b0["cin"] - b0["skip"]]
-        if not add_control(h, left):
+        done, lst = add_control(h, left)     # lst / rst: column sums of the buffer's left / right part (GroupNorm statistics)
+        if not done:
             left.copy_(h)
         for i, (res, att, up, b) in enumerate(self.dec):
             skip = hs.pop()
             right = buf[..., b["cin"] - b["skip"]:]
-            if only_mid_control or not add_control(skip, right):
+            done, rst = (False, None) if only_mid_control else add_control(skip, right)
+            if not done:
                 right.copy_(skip)
             last = i == len(self.dec) - 1
             nxt = None if last else self.plan.output[i + 1]
@@ -379,13 +400,17 @@ class ControlledUnetModel(_DiffusionNet):
                 hh, ww = 2 * hh, 2 * ww
             nbuf = None if last else cat_buf(nxt, hh, ww)
             target = None if last else nbuf[..., : nxt["cin"] - nxt["skip"]]
+            xst = (lst, rst) if (lst is not None and rst is not None) else None
             if up is None:
-                h = self._run_block(res, att, buf, emb_all, ctx_kv, out=target)
+                h, lst = self._run_block(res, att, buf, emb_all, ctx_kv, out=target, x_stats=xst)
             else:
-                h = self._run_block(res, att, buf, emb_all, ctx_kv)
-                h = ops.conv3x3(h, up, upsample=True, out=target)
+                h, _ = self._run_block(res, att, buf, emb_all, ctx_kv, x_stats=xst)
+                if GN_EPI_STATS:
+                    h, lst = ops.conv3x3(h, up, upsample=True, out=target, stats=True)
+                else:
+                    h, lst = ops.conv3x3(h, up, upsample=True, out=target), None
             buf = nbuf
-        h = ops.groupnorm(h, self.out_gn[0], self.out_gn[1], 1e-5, True)
+        h = ops.groupnorm(h, self.out_gn[0], self.out_gn[1], 1e-5, True, stats=lst)
         o = ops.conv3x3(h, self.out_conv, out_f32=True)
         return ops.nhwc_to_nchw(o, self.plan.out_ch)
 

@@ -32,6 +32,7 @@ class GemmDesc(Structure):
         ("trans_ld", c_longlong), ("trans_bstride", c_longlong),
         ("batch", c_int), ("tile", c_int),
         ("splitk", c_int), ("ws", c_void_p), ("ws_bytes", c_longlong),
+        ("stats", c_void_p), ("stats_rows", c_int),
     ]
 
 
@@ -47,6 +48,7 @@ SIGNATURES = {
     "dbir_groupnorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P],
     "dbir_groupnorm_stats": [_I, _P, _LL, _I, _I, _I, _I, _P, _P, _P],
     "dbir_groupnorm_apply": [_I, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "dbir_groupnorm_from_partials": [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "dbir_groupnorm_affine": [_I, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "dbir_layernorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _F, _P],
     "dbir_xf_tile_bytes": [], "dbir_xf_head_tiles": [], "dbir_xf_tail_tiles": [],

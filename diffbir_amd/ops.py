@@ -171,6 +171,31 @@ class _Timed:
         return False
 
 
+@dataclass
+class GnPartials:
+    """Column sums of a GEMM output emitted by its epilogue (dbir_gemm_desc.stats): buf f32 [M / rows, 2, N] — per tile of
+    `rows` rows and column: sum and sum of squares of the stored 16-bit values.  Consumed by groupnorm(..., stats=...)."""
+    buf: T
+    rows: int
+    N: int
+    M: int
+
+
+def _stats_begin(d: GemmDesc, want: bool, M: int, N: int, device):
+    if not want:
+        return None
+    st = torch.empty(((M + 63) // 64) * 2 * N, dtype=torch.float32, device=device)
+    d.stats = st.data_ptr()
+    return st
+
+
+def _stats_end(d: GemmDesc, st: Optional[T], M: int, N: int) -> Optional[GnPartials]:
+    if st is None or d.stats_rows <= 0:
+        return None
+    rows = int(d.stats_rows)
+    return GnPartials(st[: (M // rows) * 2 * N], rows, N, M)
+
+
 _TUNER = None  # tools/autotune.py installs an object with .run(d, out) while measuring tile variants
 _WS = {}       # device -> f32 split-K workspace (grown on demand, reused by every launch on that device's stream)
 _WS_KEEP = []  # superseded workspaces: captured HIP graphs (model/cldm.py) hold raw pointers into them, so a regrown
@@ -251,8 +276,9 @@ def _fill_epilogue(d: GemmDesc, pw: Optional[PackedWeight], act, act_param, out_
 
 def linear(x: T, pw: PackedWeight, out: Optional[T] = None, act: int = ACT_NONE, act_param: float = 0.0,
            out_scale: float = 1.0, residual: Optional[T] = None, rowvec: Optional[T] = None,
-           rows_per_batch: int = 0, out_f32: bool = False, tile: int = 0) -> T:
-    """out[..., :n_out] = epilogue(x[..., :K] @ W^T).  x: [..., K] 16-bit (ld >= K)."""
+           rows_per_batch: int = 0, out_f32: bool = False, tile: int = 0, stats: bool = False):
+    """out[..., :n_out] = epilogue(x[..., :K] @ W^T).  x: [..., K] 16-bit (ld >= K).
+    stats=True -> returns (out, GnPartials | None): GroupNorm column sums of the output from the epilogue."""
     _gpu(x, out, residual, rowvec)
     M, K = _rows(x), x.shape[-1]
     assert K == pw.K, f"K mismatch: x has {K}, weight has {pw.K}"
@@ -267,8 +293,9 @@ def linear(x: T, pw: PackedWeight, out: Optional[T] = None, act: int = ACT_NONE,
     d.W, d.Wrows, d.Kpad = pw.w.data_ptr(), pw.w.shape[0], pw.Kpad
     _fill_epilogue(d, pw, act, act_param, out_scale, residual, rowvec, rows_per_batch, out, out_f32)
     apply_tile_code(d, tile, x.device)  # tile id, or tile + 100 * split-K slices
-    _gemm_launch(d, (x, pw, out, residual, rowvec))
-    return out
+    st = _stats_begin(d, stats, M, pw.N, x.device)
+    _gemm_launch(d, (x, pw, out, residual, rowvec, st))
+    return (out, _stats_end(d, st, M, pw.N)) if stats else out
 
 
 def linear_t(x: T, pw: PackedWeight, L: int, out_t: T, tile: int = 0) -> T:
@@ -294,7 +321,7 @@ def linear_t(x: T, pw: PackedWeight, L: int, out_t: T, tile: int = 0) -> T:
 def conv3x3(x: T, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: bool = False,
             out: Optional[T] = None, act: int = ACT_NONE, act_param: float = 0.0, out_scale: float = 1.0,
             residual: Optional[T] = None, rowvec: Optional[T] = None, out_f32: bool = False,
-            out_hw: Optional[Tuple[int, int]] = None, tile: int = 0) -> T:
+            out_hw: Optional[Tuple[int, int]] = None, tile: int = 0, stats: bool = False):
     """3x3 convolution as implicit GEMM. x: [B, Hi, Wi, Cin] 16-bit DENSE (ld == Cin == pw.cin).
     `upsample`: nearest x2 fused into the gather. `out_hw` overrides the output extent (VAE asymmetric pad)."""
     _gpu(x, out, residual, rowvec)
@@ -316,8 +343,9 @@ def conv3x3(x: T, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: boo
     d.stride, d.pad, d.upsample = stride, pad, int(upsample)
     _fill_epilogue(d, pw, act, act_param, out_scale, residual, rowvec, Ho * Wo, out, out_f32)
     apply_tile_code(d, tile, x.device)  # tile id, or tile + 100 * split-K slices
-    _gemm_launch(d, (x, pw, out, residual, rowvec))
-    return out
+    st = _stats_begin(d, stats, B * Ho * Wo, pw.N, x.device)
+    _gemm_launch(d, (x, pw, out, residual, rowvec, st))
+    return (out, _stats_end(d, st, B * Ho * Wo, pw.N)) if stats else out
 
 
 def bmm_nt(a: T, b: T, out: T, out_scale: float = 1.0) -> T:
@@ -374,7 +402,16 @@ XfBlock = _xf.XfBlock
 pack_xf_block = _xf.pack_block
 pack_context_frags = _xf.pack_context_frags
 xf_supported = _xf.supported
-groupnorm_affine = _xf.groupnorm_affine
+
+
+def groupnorm_affine(x: T, gamma: T, beta: T, eps: float, groups: int = 32, stats=None) -> T:
+    """GroupNorm(x) as a per (sample, channel) affine map f32 [B, 2, C] for xf_head; `stats`: as in groupnorm()."""
+    B, C = x.shape[0], x.shape[-1]
+    parts = _usable_partials(stats, B, _rows(x) // B, C)
+    if parts is not None:
+        return groupnorm_stats_from_partials(parts, B, _rows(x) // B, groups, eps, gamma, beta, affine=True)
+    return _xf.groupnorm_affine(x, gamma, beta, eps, groups)
+
 
 
 def xf_head(x: T, ab: T, blk: "XfBlock", L: int):
@@ -393,11 +430,47 @@ def xf_tail(attn: T, h: T, x: T, blk: "XfBlock", kf: T, vf: T, Lk: int, scale: f
 
 
 # ------------------------------------------------------------------------------------------------ norms
-def groupnorm(x: T, gamma: T, beta: T, eps: float, silu: bool, out: Optional[T] = None, groups: int = 32) -> T:
-    """x: [B, H, W, C] (or [B, HW, C]) 16-bit; gamma/beta f32 [C]."""
+def _usable_partials(stats, B: int, HW: int, C: int):
+    """stats: GnPartials, or a (left, right) pair for a two-producer concat buffer -> (p1, p2 | None) when the column sums
+    cover the tensor exactly in whole per-sample tiles, else None (the caller computes the statistics itself)."""
+    if stats is None:
+        return None
+    parts = list(stats) if isinstance(stats, (tuple, list)) else [stats]
+    if not parts or len(parts) > 2 or any(p is None for p in parts):
+        return None
+    if any(p.rows != parts[0].rows or p.M != B * HW for p in parts) or HW % parts[0].rows or sum(p.N for p in parts) != C:
+        return None
+    return parts[0], (parts[1] if len(parts) == 2 else None)
+
+
+def groupnorm_stats_from_partials(parts, B: int, HW: int, groups: int, eps: float, gamma: Optional[T] = None,
+                                  beta: Optional[T] = None, affine: bool = False) -> T:
+    """(p1, p2 | None) -> mean_var f32 [B, 2 * groups], or with affine=True the scale | shift map f32 [B, 2, C]."""
+    p1, p2 = parts
+    C = p1.N + (p2.N if p2 is not None else 0)
+    dev = p1.buf.device
+    mv = None if affine else torch.empty((B, 2 * groups), dtype=torch.float32, device=dev)
+    ab = torch.empty((B, 2, C), dtype=torch.float32, device=dev) if affine else None
+    native.check(native.lib().dbir_groupnorm_from_partials(
+        p1.buf.data_ptr(), p1.N, None if p2 is None else p2.buf.data_ptr(), 0 if p2 is None else p2.N, p1.rows, B, HW,
+        groups, eps, None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(),
+        None if mv is None else mv.data_ptr(), None if ab is None else ab.data_ptr(), _stream()),
+        "dbir_groupnorm_from_partials")
+    return ab if affine else mv
+
+
+def groupnorm(x: T, gamma: T, beta: T, eps: float, silu: bool, out: Optional[T] = None, groups: int = 32,
+              stats=None) -> T:
+    """x: [B, H, W, C] (or [B, HW, C]) 16-bit; gamma/beta f32 [C].
+    stats: the producing GEMM's epilogue column sums (GnPartials, or a (left, right) pair for a concat buffer): the
+    statistics pass over x is skipped (GroupNorm statistics from the producer)."""
     _gpu(x, gamma, beta, out)
     B, C = x.shape[0], x.shape[-1]
     HW = _rows(x) // B
+    parts = _usable_partials(stats, B, HW, C)
+    if parts is not None:
+        mv = groupnorm_stats_from_partials(parts, B, HW, groups, eps)
+        return groupnorm_apply(x, gamma, beta, mv, eps, silu, out=out, groups=groups)
     if out is None:
         out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     nchunk = native.lib().dbir_groupnorm_nchunk(HW, C)

@@ -117,8 +117,17 @@ typedef struct dbir_gemm_desc {
   int splitk;
   void* ws;
   long long ws_bytes;
+  /* GroupNorm statistics of the OUTPUT straight from the epilogue (GroupNorm32 util.py:191-193 follows almost every
+   * convolution of the UNet: unet.py:149-153,173-180, attention.py:48-51): stats != NULL asks the launched kernel for the
+   * per (row tile, column) sums of the STORED 16-bit values and of their squares, stats[tile_m][2][N] f32 (room for
+   * ceil(M / 64) * 2 * N floats).  IN/OUT: on return stats_rows = the rows per tile used (the launched kernel's tile
+   * height; M % stats_rows == 0), or 0 when this launch could not produce them (split-K, GEGLU, transposed / f32 store,
+   * batch > 1, the persistent / generic kernels, ragged M) — the caller then runs dbir_groupnorm_stats instead.
+   * dbir_groupnorm_from_partials turns the sums of one or two column-adjacent producers into mean / variance. */
+  float* stats;
+  int stats_rows;
 } dbir_gemm_desc;
-int dbir_gemm(const dbir_gemm_desc* d, void* stream);
+int dbir_gemm(dbir_gemm_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * dbir_attention — flash-style softmax(Q K^T * scale) V, head_dim 64, no mask.
@@ -169,6 +178,13 @@ int dbir_groupnorm_apply(int dtype, const void* x, long long ldx, void* y, long 
  * dbir_xf_head, which applies it while it loads its activation panel (same workspace contract as dbir_groupnorm). */
 int dbir_groupnorm_affine(int dtype, const void* x, long long ldx, int B, int HW, int C, int groups, float eps,
                           const float* gamma, const float* beta, float* workspace, float* scale_shift, void* stream);
+/* dbir_groupnorm_from_partials: GroupNorm statistics from the column sums that dbir_gemm epilogues emit (dbir_gemm_desc.stats):
+ * the normalised tensor [B, HW, C] is the column concatenation of producer 1 (N1 columns) and producer 2 (N2 columns, or
+ * NULL / 0): p[tile][2][N] with `rows` rows per tile (HW % rows == 0).  Writes mean_var f32 [B][mean(groups) | biased
+ * var(groups)] (the layout dbir_groupnorm_apply takes) and / or scale_shift f32 [B][2][C] (dbir_xf_head); either may be NULL. */
+int dbir_groupnorm_from_partials(const float* p1, int N1, const float* p2, int N2, int rows, int B, int HW, int groups,
+                                 float eps, const float* gamma, const float* beta, float* mean_var, float* scale_shift,
+                                 void* stream);
 /* dbir_layernorm: nn.LayerNorm rows (attention.py:255-257; swinir.py:205,211,764), eps 1e-5.
  * Normalises over the first C columns; columns [C, Cpad) of y are written as zero. */
 int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,

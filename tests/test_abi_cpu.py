@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_gemm_desc_layout_matches_header(tmp_path):
     from diffbir_amd.native import GemmDesc
-    fields = ["mode", "tile", "splitk", "ws", "ws_bytes", "C", "trans_bstride"]
+    fields = ["mode", "tile", "splitk", "ws", "ws_bytes", "C", "trans_bstride", "stats", "stats_rows"]
     prog = tmp_path / "sz.c"
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu", sizeof(dbir_gemm_desc));%s return 0;}'
                     % (os.path.join(ROOT, "include", "dbir.h"),

@@ -577,6 +577,73 @@ def test_pers_rejects_ineligible(tile):
         ops.conv3x3(x, pc, tile=tile)
 
 
+# ------------------------------------------------------------------------------------------------ GroupNorm statistics from GEMM epilogues
+def _check_partials(name, st, stored, rows_total):
+    """st.buf == column sums / sums of squares of the STORED 16-bit tensor per tile of st.rows rows"""
+    N = stored.shape[-1]
+    assert st.rows in (64, 128, 256) and rows_total % st.rows == 0 and st.M == rows_total and st.N == N
+    o = stored.float().reshape(-1, st.rows, N).double()
+    got = st.buf.reshape(-1, 2, N).double()
+    assert got.shape[0] == rows_total // st.rows
+    e1 = (got[:, 0] - o.sum(1)).abs().max().item() / o.abs().sum(1).max().item()
+    e2 = (got[:, 1] - (o * o).sum(1)).abs().max().item() / (o * o).sum(1).max().item()
+    assert e1 < 2e-6 and e2 < 2e-6, f"{name}: column sums off by {e1:.2e} / {e2:.2e} (f32 accumulation of 16-bit values)"
+
+
+STATS_TILES = [0] + [t for t in GLDS_TILES] + [50, 51, 52, 53]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", STATS_TILES)
+def test_epilogue_group_norm_statistics(tile, dtype):
+    """dbir_gemm_desc.stats: the column sums / sums of squares the epilogue emits per output tile equal those of the stored
+    16-bit tensor; GroupNorm from them (two column-adjacent producers = a decoder concat buffer) equals GroupNorm with its
+    own statistics pass; launches that cannot produce them report so (the caller falls back)."""
+    B, H, W, Cin, N1, N2 = 2, 32, 32, 128, 320, 192
+    x = rnd(B, H, W, Cin, dtype=dtype)
+    w1, b1 = rnd(N1, Cin, 3, 3, dtype=torch.float32, s=(9 * Cin) ** -0.5, seed=1), rnd(N1, dtype=torch.float32, seed=2)
+    pc = ops.pack_conv3x3(w1.cpu(), b1.cpu(), dtype, DEV)
+    res = rnd(B, H, W, N1, dtype=dtype, seed=3) + 2.0
+    emb = rnd(B, N1, dtype=dtype, seed=4)
+    buf = torch.zeros(B, H, W, N1 + N2, dtype=dtype, device=DEV)
+    out, st = ops.conv3x3(x, pc, residual=res, rowvec=emb, out=buf[..., :N1], tile=tile, stats=True)
+    ref = ops.conv3x3(x, pc, residual=res, rowvec=emb, tile=tile)
+    assert torch.equal(out, ref), "asking for statistics must not change the stored values"
+    assert st is not None, f"tile {tile}: a whole-tile 16-bit row-major launch must emit statistics"
+    _check_partials(f"conv t{tile}", st, out, B * H * W)
+    # second producer (a linear with scale + residual, as the fused control injection) -> the buffer's right part
+    f = rnd(B * H * W, 256, dtype=dtype, seed=5)
+    w2, b2 = rnd(N2, 256, dtype=torch.float32, s=1 / 16, seed=6), rnd(N2, dtype=torch.float32, seed=7)
+    pl = ops.pack_linear(w2.cpu(), b2.cpu(), dtype, DEV)
+    skip = rnd(B, H, W, N2, dtype=dtype, seed=8) - 3.0      # an offset: |mean| >> std in the right half
+    lt = tile if tile < 50 else 0
+    o2, st2 = ops.linear(f, pl, out_scale=0.7, residual=skip, out=buf[..., N1:], tile=lt, stats=True)
+    assert st2 is not None
+    _check_partials(f"linear t{lt}", st2, o2, B * H * W)
+    gam, bet = 1 + 0.1 * rnd(N1 + N2, dtype=torch.float32, seed=9), 0.1 * rnd(N1 + N2, dtype=torch.float32, seed=10)
+    plain = ops.groupnorm(buf, gam, bet, 1e-5, True)
+    mv_ref = ops.groupnorm_stats(buf)
+    if st2.rows == st.rows:
+        mv = ops.groupnorm_stats_from_partials((st, st2), B, H * W, 32, 1e-5)
+        err = ((mv - mv_ref).abs() / (mv_ref.abs() + 1e-3)).max().item()
+        assert err < 2e-5, f"mean / variance from the epilogue sums vs the statistics kernel: {err:.2e}"
+        fused = ops.groupnorm(buf, gam, bet, 1e-5, True, stats=(st, st2))
+        assert (fused.float() - plain.float()).abs().max().item() <= 2 * TOL[dtype][1] * 1e-1 * plain.float().abs().max().item()
+        ab = ops.groupnorm_affine(buf, gam, bet, 1e-5, stats=(st, st2))
+        check("groupnorm_affine from epilogue statistics", ab, emu.groupnorm_affine(buf, gam, bet, 1e-5), torch.float32, 2.0)
+    # statistics that do not cover the consumer's tensor exactly are ignored (own statistics pass)
+    assert torch.equal(ops.groupnorm(buf, gam, bet, 1e-5, True, stats=(st, None)), plain)
+    assert torch.equal(ops.groupnorm(buf[..., :N1 + 64], gam[:N1 + 64], bet[:N1 + 64], 1e-5, True, stats=(st, st2), groups=32),
+                       ops.groupnorm(buf[..., :N1 + 64], gam[:N1 + 64], bet[:N1 + 64], 1e-5, True, groups=32))
+    # launches that cannot emit them (ragged row tiles, split-K, f32 store) say so and the consumer falls back
+    xr = rnd(1, 30, 30, Cin, dtype=dtype, seed=11)
+    outr, none1 = ops.conv3x3(xr, pc, stats=True)
+    assert none1 is None and torch.equal(outr, ops.conv3x3(xr, pc))
+    if tile in (5, 12):
+        _, none2 = ops.conv3x3(x, pc, tile=tile + 200, stats=True)
+        assert none2 is None
+
+
 # ------------------------------------------------------------------------------------------------ fused transformer block
 def _xf_weights(seed=0, gain=1.0):
     """Random weights of one C = 320 transformer block (f32, CPU), by the short names of xformer.pack_block."""

@@ -104,6 +104,30 @@ def test_tiny_pipeline_vs_reference_golden(golden_dir, name, dcfg, lqspec, steps
     assert out.shape == ref.shape and psnr >= min_psnr, psnr
 
 
+def test_golden_under_first_use_autotune(golden_dir, tmp_path, monkeypatch):
+    """Table misses tuned on the device at first use (diffbir_amd/autotune.py, on by default outside the tests): the tuned
+    run and the replay from the written cache both meet the reference golden at the fp16 bar, and every kept winner was
+    validated against the default kernel on the launch's real operands."""
+    from diffbir_amd import autotune
+    monkeypatch.setenv("DBIR_AUTOTUNE_CACHE", str(tmp_path))
+    monkeypatch.setattr(autotune, "_cache", None)
+    monkeypatch.setattr(autotune, "ENABLED", True)
+    before = dict(autotune.stats)
+    dev = _dev()
+    name, dcfg, lqspec, steps, sampler, seed, kw = CASES[4]      # 600 x 712 padded input: shapes the table does not hold
+    ref = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))[name]
+    pipe, cldm, swin = build_engine("tiny", dcfg, dev, torch.float16)
+    first = run_pipe(pipe, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+    tuned = autotune.stats["tuned"] - before["tuned"]
+    again = run_pipe(pipe, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+    p1, p2 = cases.psnr_u8(first, ref), cases.psnr_u8(again, ref)
+    REPORT["tiny_autotune_first_use"] = dict(keys_tuned=tuned, psnr_first=p1, psnr_cached=p2)
+    assert tuned > 0 and autotune.stats["tuned"] - before["tuned"] == tuned, "second run must hit the cache"
+    assert p1 >= 45.0 and p2 >= 45.0, (p1, p2)
+    autotune.save()
+    assert os.listdir(tmp_path), "winners are kept for later processes"
+
+
 @pytest.mark.parametrize("name", sorted(OPTION_CASES))
 def test_tiny_pipeline_options_vs_reference_golden(golden_dir, name):
     """option paths of Pipeline.run (start point, noise augmentation, CFG rescale / off, strength, tiled cleaner,
