@@ -248,9 +248,17 @@ def test_tiled_equals_untiled_when_single_tile():
     assert cases.psnr_u8(a, b) > 48.0
 
 
-def test_batch_independence():
+@pytest.mark.parametrize("epilogue_stats", [False, True])
+def test_batch_independence(monkeypatch, epilogue_stats):
     """images are independent units (the data-parallel sharding property): a batch of 2 equals two batches of 1
-    given the same per-sample noise."""
+    given the same per-sample noise.  With GroupNorm statistics taken by the statistics kernel the two are bit-identical
+    on this configuration (same tiles for both row counts).  With the statistics taken from the producing GEMM's epilogue
+    (default) a launch is eligible or not depending on its row count, i.e. the two batch sizes sum the same numbers in a
+    different order in some GroupNorms: the tiny network with random weights and CFG 4 turns ONE different rounding
+    anywhere into 51.3 dB on the u8 output (profiles/r3_gn_epilogue_stats_ab.txt: the same figure for any perturbation,
+    e.g. another tile for one GEMM) — 50 dB is that floor, the bar against the fp32 reference stays 45 dB (above)."""
+    from diffbir_amd.model import unet
+    monkeypatch.setattr(unet, "GN_EPI_STATS", epilogue_stats)
     dev = _dev()
     pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
     lq = cases.make_lq(5, 2, 512, 512)
@@ -269,7 +277,10 @@ def test_batch_independence():
         it = iter([d[i:i + 1] for d in draws])
         pipe.randn = lambda shape: next(it)
         one = pipe.run(lq[i:i + 1], *args)
-        assert cases.psnr_u8(one, both[i:i + 1]) > 55.0
+        psnr = cases.psnr_u8(one, both[i:i + 1])
+        REPORT[f"tiny_batch_independence_{'epilogue' if epilogue_stats else 'kernel'}_stats_{i}"] = \
+            dict(psnr=float(min(psnr, 999.0)), bit_identical=bool((one == both[i:i + 1]).all()))
+        assert psnr > (50.0 if epilogue_stats else 55.0), psnr
 
 
 def test_full_config_batch_independence_and_fused_blocks(full_engine):

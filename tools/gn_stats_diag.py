@@ -44,6 +44,13 @@ def main():
             res[on, "b2"] = run(pipe, lq, draws, slice(0, 2))
             res[on, "b1"] = [run(pipe, lq, draws, slice(i, i + 1)) for i in range(2)]
         p = cases.psnr_u8
+        unet.GN_EPI_STATS = False
+        cldm.reset_graphs()
+        rep2 = run(pipe, lq, draws, slice(0, 2))
+        rep1 = run(pipe, lq, draws, slice(0, 1))
+        print(cfg, "same settings run twice (stats off): batch 2 bit-identical:", bool((rep2 == res[False, "b2"]).all()),
+              " batch 1 bit-identical:", bool((rep1 == res[False, "b1"][0]).all()),
+              " differing u8 values:", int((rep2 != res[False, "b2"]).sum()), int((rep1 != res[False, "b1"][0]).sum()))
         for on in (False, True):
             print(cfg, f"epilogue stats {'on ' if on else 'off'}: batch 2 vs batch 1:",
                   [round(p(res[on, 'b1'][i], res[on, 'b2'][i:i + 1]), 2) for i in range(2)])
