@@ -76,6 +76,61 @@ __global__ __launch_bounds__(1024) void k(int iters, float c, float* sink) {
   if (s == 123.456f) sink[0] = s;
 }
 
+// sweep: NM MFMAs per round, each followed by FE v_exp_f32 and FF v_fma_f32 (program order, sched_barrier between gaps)
+template <int FE, int FF>
+__global__ __launch_bounds__(1024) void ksweep(int iters, float c, float* sink) {
+  const int lane = threadIdx.x & 63;
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  f16x8 a, b;
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (_Float16)(0.001f * (lane + e));
+    b[e] = (_Float16)(0.002f * (lane - e));
+  }
+  float v[16];
+  for (int e = 0; e < 16; ++e) v[e] = -0.01f * (lane + e);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i & 3], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < FE; ++e) v[(i * FE + e) & 15] = __builtin_amdgcn_exp2f(v[(i * FE + e) & 15]);
+#pragma unroll
+      for (int e = 0; e < FF; ++e) v[(i * FF + e + 5) & 15] = __builtin_fmaf(v[(i * FF + e + 5) & 15], c, 0.25f);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) s += acc[j][r];
+  for (int e = 0; e < 16; ++e) s += v[e];
+  if (s == 123.456f) sink[0] = s;
+}
+
+template <int FE, int FF>
+static void sweep(int iters, float* sink) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  double cyc[2];
+  for (int w = 1; w <= 2; ++w) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL((ksweep<FE, FF>), dim3(256), dim3(256 * w), 0, 0, iters, 0.999f, sink);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (rep > 0 && ms < best) best = ms;
+    }
+    cyc[w - 1] = best * 1e-3 * 2.4e9 / iters / 16 / w;
+  }
+  printf("per MFMA gap: %d v_exp_f32 + %2d v_fma_f32   nominal cycles per MFMA and wave: %6.1f (1 wave/SIMD)  %6.1f (2 waves/SIMD)\n", FE, FF,
+         cyc[0], cyc[1]);
+}
+
 template <int MODE, int NM, int NE, int NF>
 static double run(int threads, int blocks_per_cu, int iters, float* sink, const char* what) {
   hipEvent_t e0, e1;
@@ -118,5 +173,23 @@ int main() {
   // 4 waves per SIMD via 2 workgroups of 512
   run<MODE_BOTH_SEQ, NM, NE, NF>(512, 2, iters, sink, "MFMA block then VALU block, 2 workgroups x 512");
   run<MODE_SPLIT_WAVES, NM, NE, NF>(512, 2, iters, sink, "half MFMA / half VALU waves, 2 workgroups x 512");
+  printf("\nfillers per MFMA gap (16 MFMAs per round, 4 accumulator chains)\n");
+  sweep<0, 0>(iters, sink);
+  sweep<0, 1>(iters, sink);
+  sweep<0, 2>(iters, sink);
+  sweep<0, 3>(iters, sink);
+  sweep<0, 4>(iters, sink);
+  sweep<0, 5>(iters, sink);
+  sweep<0, 6>(iters, sink);
+  sweep<0, 8>(iters, sink);
+  sweep<0, 10>(iters, sink);
+  sweep<0, 12>(iters, sink);
+  sweep<0, 16>(iters, sink);
+  sweep<1, 0>(iters, sink);
+  sweep<2, 0>(iters, sink);
+  sweep<3, 0>(iters, sink);
+  sweep<4, 0>(iters, sink);
+  sweep<2, 4>(iters, sink);
+  sweep<2, 7>(iters, sink);
   return 0;
 }
