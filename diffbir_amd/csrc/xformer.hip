@@ -42,23 +42,44 @@
 
 namespace {
 
-constexpr int XC = 320;                 // channels of the level
-constexpr int XBM = 128;                // panel rows
+// Per-width configuration.  C = 320 (64x64 level): WM 4 x WN 2 waves over a 128-row panel; C = 640 (32x32 level): WM 2 x
+// WN 4 over a 64-row panel (the panel image is 80 KB either way) — a wave owns 32 rows x 160 columns in both.  A weight tile
+// is always 20 pieces of 1 KB: [GNKS k-steps][C / 32 column blocks] for the N = C GEMMs and the feed-forward output
+// projection, [5 k-steps][4 blocks = (value, gate) x 2 hidden blocks] for the GEGLU projection; at WN = 4 a feed-forward
+// chunk (32 WN hidden units) takes NSUB = 2 such tile runs, each multiplied by the half of the waves that owns its blocks.
+template <int CC>
+struct XfCfg {
+  static_assert(CC == 320 || CC == 640, "fused transformer kernels: C = 320 or 640");
+  static constexpr int C = CC, WN = CC / 160, WM = 8 / WN, BM = 32 * WM, KS = CC / 16, HID = 4 * CC, HEADS = CC / 64;
+  static constexpr int NB = CC / 32;              // column blocks of an N = C GEMM
+  static constexpr int GNKS = 20 / NB;            // k-steps per tile of an N = C GEMM
+  static constexpr int GNT = KS / GNKS;           // tiles of a C x C GEMM
+  static constexpr int NSUB = WN / 2;             // GEGLU projection runs per feed-forward chunk
+  static constexpr int CHH = 32 * WN;             // hidden units per chunk
+  static constexpr int CH = HID / CHH;            // chunks (20)
+  static constexpr int F1T = KS / 5;              // tiles per GEGLU projection run
+  static constexpr int GKST = CHH / 16;           // k-steps of the chunk image
+  static constexpr int F2T = GKST / GNKS;         // tiles of a chunk's output projection
+  static constexpr int TAIL_TILES = 4 * GNT + CH * (NSUB * F1T + F2T);  // out1, q2, out2, CH x (FF1 + FF2), proj_out
+  static constexpr int HEAD_TILES = 4 * GNT;                            // proj_in, q, k, v
+};
 constexpr int XNT = 512;                // threads per workgroup
-constexpr int XKS = XC / 16;            // MFMA k-steps over C
-constexpr int XHID = 4 * XC;            // GEGLU hidden width
-constexpr int XCH = XHID / 64;          // feed-forward chunks (64 hidden units each)
-constexpr int XHEADS = XC / 64;
 constexpr int TILE_W = 20480, TILE_AUX = 512, TILE_BYTES = TILE_W + TILE_AUX;
-constexpr int X_BYTES = XBM * XC * 2;   // 81920
+constexpr int X_BYTES = 128 * 320 * 2;  // 81920 = BM * C * 2 for both configurations
 constexpr int NSLOT = 3;
 constexpr int RING_OFF = X_BYTES;
-constexpr int GB_OFF = RING_OFF + NSLOT * TILE_BYTES;  // 144896: GEGLU chunk [4][4][64][16 B] / LayerNorm partials
+constexpr int GB_OFF = RING_OFF + NSLOT * TILE_BYTES;  // 144896: GEGLU chunk [WM][GKST][64][16 B] / LayerNorm partials
 constexpr int GB_BYTES = 16384;
 constexpr int XF_LDS = GB_OFF + GB_BYTES;              // 161280 <= 163840
-constexpr int TAIL_TILES = 10 + 10 + 10 + XCH * 6 + 10;  // out1, q2, out2, 20 x (4 FF1 + 2 FF2), proj_out
-constexpr int HEAD_TILES = 40;                           // proj_in, q, k, v
 constexpr int XKB = 3, XLKP = 96;       // padded text context: 3 key blocks of 32
+// the configuration's constants under the names the macros below use (declared at the top of each kernel)
+#define XF_CFG(CC)                                                                                                      \
+  using G_ = XfCfg<CC>;                                                                                                 \
+  constexpr int XC = G_::C, XBM = G_::BM, XKS = G_::KS, XCH = G_::CH, XHEADS = G_::HEADS, XWM = G_::WM, XWN = G_::WN,   \
+                XNB = G_::NB, GNKS = G_::GNKS, GNT = G_::GNT, NSUB = G_::NSUB, F1T = G_::F1T, GKST = G_::GKST,          \
+                F2T = G_::F2T, TAIL_TILES = G_::TAIL_TILES, HEAD_TILES = G_::HEAD_TILES;                                \
+  (void)XCH; (void)XHEADS; (void)NSUB; (void)F1T; (void)GKST; (void)F2T; (void)TAIL_TILES; (void)HEAD_TILES;           \
+  (void)XWM; (void)GNT; (void)XNB; (void)GNKS
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -173,7 +194,7 @@ struct XfParams {
 //   XF_RUN_BODY : NT tiles of NKS k-steps; A-side fragment of (tile i, k-step ks) at AADDR(i, ks) (lane offset folded
 //                 in), W fragments of block jl at tbase + (ks * PSTR + WFIRST + jl) * 1024 + lane * 16
 #define XF_READ_FRAGS(SET, NJ, AADDR_, WPIECE)                                                                    \
-  if (!(abl & 32)) {                                                                                              \
+  if (act_ && !(abl & 32)) {                                                                                              \
     xfr[SET] = *reinterpret_cast<const typename T::vec8*>(AADDR_);                                                \
     _Pragma("unroll") for (int jl = 0; jl < NJ; ++jl) wfr[SET][jl] =                                              \
         *reinterpret_cast<const typename T::vec8*>(tbase + ((WPIECE) + jl) * 1024 + lane16);                      \
@@ -204,20 +225,20 @@ struct XfParams {
         if (issued < total) XF_STAGE(NTILES);                                                                     \
       }                                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                                          \
-      if (!(abl & 16)) {                                                                                          \
+      if (act_ && !(abl & 16)) {                                                                                  \
         _Pragma("unroll") for (int jl = 0; jl < NJ; ++jl) ACC[jl] = T::mfma32(wfr[cur_][jl], xfr[cur_], ACC[jl]); \
       }                                                                                                           \
     }                                                                                                             \
   } while (0)
 
-// a whole N = 320, K = 320 GEMM over the panel in X: 10 tiles of (10 blocks x 2 k-steps)
-#define XF_A_X2(i, ks) (smem + (wm * XKS + 2 * (i) + (ks)) * 1024 + lane16)
+// a whole N = C, K = C GEMM over the panel in X: GNT tiles of (C / 32 blocks x GNKS k-steps)
+#define XF_A_XG(i, ks) (smem + (wm * XKS + GNKS * (i) + (ks)) * 1024 + lane16)
 #define XF_A_X5(i, ks) (smem + (wm * XKS + 5 * (i) + (ks)) * 1024 + lane16)
-#define XF_A_GB(i, ks) (smem + GB_OFF + (wm * 4 + 2 * (i) + (ks)) * 1024 + lane16)
-#define XF_GEMM320(NTILES)                                                                                        \
+#define XF_A_GB(i, ks) (smem + GB_OFF + (wm * GKST + GNKS * (i) + (ks)) * 1024 + lane16)
+#define XF_GEMMCC(NTILES)                                                                                         \
   do {                                                                                                            \
-    XF_RUN_BEGIN(5, XF_A_X2, 5 * wn, NTILES);                                                                     \
-    XF_RUN_BODY(10, 2, 5, 10, XF_A_X2, 5 * wn, acc, NTILES);                                                      \
+    XF_RUN_BEGIN(5, XF_A_XG, 5 * wn, NTILES);                                                                     \
+    XF_RUN_BODY(GNT, GNKS, 5, XNB, XF_A_XG, 5 * wn, acc, NTILES);                                                 \
   } while (0)
 
 // byte offset inside a fragment-major operand image with KST k-steps per 32-row block of the 4 consecutive columns
@@ -340,16 +361,20 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
     s_ += __shfl_xor(s_, 32, 64);                                                                                 \
     if (hi == 0) red_[wn * XBM + row_] = s_;                                                                      \
     xbarrier();                                                                                                   \
-    const float mean_ = (red_[row_] + red_[XBM + row_]) * (1.0f / XC);                                            \
+    float mean_ = 0.f;                                                                                            \
+    _Pragma("unroll") for (int w_ = 0; w_ < XWN; ++w_) mean_ += red_[w_ * XBM + row_];                            \
+    mean_ *= (1.0f / XC);                                                                                         \
     float q_ = 0.f;                                                                                               \
     _Pragma("unroll") for (int j = 0; j < 5; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) {                \
       acc[j][r] -= mean_;                                                                                         \
       q_ += acc[j][r] * acc[j][r];                                                                                \
     }                                                                                                             \
     q_ += __shfl_xor(q_, 32, 64);                                                                                 \
-    if (hi == 0) red_[2 * XBM + wn * XBM + row_] = q_;                                                            \
+    if (hi == 0) red_[(XWN + wn) * XBM + row_] = q_;                                                              \
     xbarrier();                                                                                                   \
-    const float rstd_ = rsqrtf((red_[2 * XBM + row_] + red_[3 * XBM + row_]) * (1.0f / XC) + 1e-5f);              \
+    float var_ = 0.f;                                                                                             \
+    _Pragma("unroll") for (int w_ = 0; w_ < XWN; ++w_) var_ += red_[(XWN + w_) * XBM + row_];                     \
+    const float rstd_ = rsqrtf(var_ * (1.0f / XC) + 1e-5f);                                                       \
     int xb_ = xoff(wm, XKS, 160 * wn + 4 * hi, lq);                                                               \
     XF_OPAQUE(xb_);                                                                                               \
     _Pragma("unroll") for (int j = 0; j < 5; ++j) _Pragma("unroll") for (int g = 0; g < 4; ++g) {                 \
@@ -411,13 +436,17 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
 // ===============================================================================================================
 // xf_tail
 // ===============================================================================================================
-template <typename T, int DBG>  // 0 = production, 1 = intermediate dumps (tests), 2 = section timing (tools/xf_anatomy.py)
+template <typename T, int DBG, int CC>  // DBG 0 = production, 1 = intermediate dumps (tests), 2 = section timing (tools/xf_anatomy.py)
 __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  XF_CFG(CC);
+  constexpr bool act_ = true;  // (shadowed inside the GEGLU projection runs: waves that own none of a run's blocks)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  // C = 320: (wm, wn) = (wave / 2, wave % 2); C = 640: (wave % 2, wave / 2) — the waves of one column-group pair
+  // (wn / 2) then sit on four different SIMDs, which a GEGLU projection run relies on
+  const int wm = XWN == 2 ? wave >> 1 : wave & 1, wn = XWN == 2 ? wave & 1 : wave >> 1;
   const int lq = lane & 31, hi = lane >> 5;
   const int lane16 = lane * 16;
 
@@ -480,7 +509,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
     landed = issued;
     XF_TS(0);
     // ---------------- phase 1: h1 = attn @ Wo1^T + b + h;  X = LayerNorm2(h1) ----------------
-    XF_GEMM320(TAIL_TILES);
+    XF_GEMMCC(TAIL_TILES);
     XF_TS(1);
     XF_ROUND_TO_HRES();
     if (DBG == 1 && p.stop_after == 11) { XF_DUMP_HRES(); XF_SKIP_REST(TAIL_TILES); continue; }
@@ -491,7 +520,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
     if (DBG == 1 && p.stop_after == 1) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
     XF_TS(2);
     // ---------------- phase 2: q = LN2(h1) @ Wq^T  -> X ----------------
-    XF_GEMM320(TAIL_TILES);
+    XF_GEMMCC(TAIL_TILES);
     XF_TS(3);
     uint4 kfr[12];  // context K fragments of this wave's first cross-attention unit (rowblk wave / 5, head wave % 5)
     {
@@ -508,7 +537,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
     // (K fragments of a unit are fetched one unit ahead — the first ones under the q store above — and V^T fragments
     // behind the S^T MFMAs, under the softmax arithmetic: the loads are L2 hits of ~1 us that stood in front of every
     // MFMA group before: 13 us per panel)
-    for (int u = wave; u < 4 * XHEADS; u += 8) {
+    for (int u = wave; u < XWM * XHEADS; u += 8) {
       const int rb = u / XHEADS, hd = u - rb * XHEADS;
       typename T::vec8 qf[4];
 #pragma unroll
@@ -530,7 +559,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
       uint4 vfr[12];
 #pragma unroll
       for (int i = 0; i < 12; ++i) vfr[i] = xld_u4(vf_srd, lane16, vf_so + i * 1024);
-      if (u + 8 < 4 * XHEADS) {  // next unit of this wave: (u + 8) % 5 = (hd + 3) % 5
+      if (u + 8 < XWM * XHEADS) {  // next unit of this wave
         const int kf_so = (b * XHEADS + (u + 8) % XHEADS) * (XKB * 4) * 1024;
 #pragma unroll
         for (int i = 0; i < 12; ++i) kfr[i] = xld_u4(kf_srd, lane16, kf_so + i * 1024);
@@ -593,7 +622,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
     if (DBG == 1 && p.stop_after == 3) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
     XF_TS(6);
     // ---------------- phase 4: h2 = a @ Wo2^T + b + h1;  X = LayerNorm3(h2) ----------------
-    XF_GEMM320(TAIL_TILES);
+    XF_GEMMCC(TAIL_TILES);
     XF_TS(7);
     XF_ROUND_TO_HRES();
     if (DBG == 1 && p.stop_after == 14) { XF_DUMP_HRES(); XF_SKIP_REST(TAIL_TILES); continue; }
@@ -605,29 +634,36 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
     landed = issued;
     if (DBG == 1 && p.stop_after == 4) { XF_DUMP_X(); XF_SKIP_REST(TAIL_TILES); continue; }
     XF_TS(8);
-    // ---------------- phase 5: GEGLU feed-forward, 20 chunks of 64 hidden units ----------------
+    // ---------------- phase 5: GEGLU feed-forward, 20 chunks of 32 WN hidden units ----------------
     for (int cch = 0; cch < XCH; ++cch) {
       f32x16 gacc[2];
-      XF_RUN_ACQ(2, XF_A_X5, 2 * wn);
-      {  // G := GEGLU projection bias (f32 side data of the chunk's first tile): [wn][value | gate][32]
-        const float* bz = reinterpret_cast<const float*>(tbase + TILE_W) + wn * 64 + 4 * hi;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+      for (int sub = 0; sub < NSUB; ++sub) {
+        // run `sub` holds the (value, gate) blocks of the column groups 2 sub, 2 sub + 1: the other waves only keep the ring
+        // moving (acquire / refill) — the run is bound by the weight stream either way
+        const bool act_ = NSUB == 1 || (wn >> 1) == sub;
+        const int wl = wn & 1;
+        XF_RUN_ACQ(2, XF_A_X5, 2 * wl);
+        if (act_) {  // G := GEGLU projection bias (f32 side data of the run's first tile): [wl][value | gate][32]
+          const float* bz = reinterpret_cast<const float*>(tbase + TILE_W) + wl * 64 + 4 * hi;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 b_ = *reinterpret_cast<const float4*>(bz + blk * 32 + 8 * g);
-            gacc[blk][4 * g + 0] = b_.x;
-            gacc[blk][4 * g + 1] = b_.y;
-            gacc[blk][4 * g + 2] = b_.z;
-            gacc[blk][4 * g + 3] = b_.w;
-          }
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 b_ = *reinterpret_cast<const float4*>(bz + blk * 32 + 8 * g);
+              gacc[blk][4 * g + 0] = b_.x;
+              gacc[blk][4 * g + 1] = b_.y;
+              gacc[blk][4 * g + 2] = b_.z;
+              gacc[blk][4 * g + 3] = b_.w;
+            }
+        }
+        if (issued < total) XF_STAGE(TAIL_TILES);  // (behind the side-data reads: hipcc drains vmcnt in front of an LDS read
+                                                   // that follows a direct-to-LDS load it cannot tell apart from the ring)
+        XF_RUN_BODY(F1T, 5, 2, 4, XF_A_X5, 2 * wl, gacc, TAIL_TILES);
       }
-      if (issued < total) XF_STAGE(TAIL_TILES);  // (behind the side-data reads: hipcc drains vmcnt in front of an LDS read
-                                                 // that follows a direct-to-LDS load it cannot tell apart from the ring)
-      XF_RUN_BODY(4, 5, 2, 4, XF_A_X5, 2 * wn, gacc, TAIL_TILES);
       XF_TS(9);
-      // g = value * gelu(gate) -> GEGLU chunk image [rowblk 4][kstep 4] (its previous readers passed a barrier since)
-      int gb = GB_OFF + xoff(wm, 4, 32 * wn + 4 * hi, lq);
+      // g = value * gelu(gate) -> GEGLU chunk image [rowblk WM][kstep GKST] (its previous readers passed a barrier since)
+      int gb = GB_OFF + xoff(wm, GKST, 32 * wn + 4 * hi, lq);
       XF_OPAQUE(gb);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -641,7 +677,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
       }
       XF_TS(10);
       XF_RUN_BEGIN(5, XF_A_GB, 5 * wn, TAIL_TILES);  // its barrier publishes the chunk
-      XF_RUN_BODY(2, 2, 5, 10, XF_A_GB, 5 * wn, acc, TAIL_TILES);
+      XF_RUN_BODY(F2T, GNKS, 5, XNB, XF_A_GB, 5 * wn, acc, TAIL_TILES);
       XF_TS(11);
     }
     // ---------------- phase 6: h3 -> X; acc = x + b_po; out = h3 @ Wpo^T + ... ----------------
@@ -657,7 +693,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
     xwait<0>();
     landed = issued;
     XF_TS(12);
-    XF_GEMM320(TAIL_TILES);
+    XF_GEMMCC(TAIL_TILES);
     XF_TS(13);
     XF_ROW_STORE(out_srd, p.ldout, row0, 0);
     XF_TS(14);
@@ -673,13 +709,15 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
 // xf_head: x -> GroupNorm apply -> proj_in -> h (stored) -> LayerNorm1 -> q | k (stored [M, 2C]) and v^T (stored
 // transposed per sample for the flash-attention kernel)
 // ===============================================================================================================
-template <typename T>
+template <typename T, int CC>
 __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  XF_CFG(CC);
+  constexpr bool act_ = true;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = XWN == 2 ? wave >> 1 : wave & 1, wn = XWN == 2 ? wave & 1 : wave >> 1;
   const int lq = lane & 31, hi = lane >> 5;
   const int lane16 = lane * 16;
 
@@ -742,7 +780,7 @@ __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
     xwait<0>();
     landed = issued;
     // ---------------- phase 1: h = GN(x) @ Wpi^T + b -> HBM;  X = LayerNorm1(h) ----------------
-    XF_GEMM320(HEAD_TILES);
+    XF_GEMMCC(HEAD_TILES);
     XF_ROW_STORE(h_srd, p.ldh, row0, 0);
 #pragma unroll
     for (int j = 0; j < 5; ++j)
@@ -755,15 +793,15 @@ __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       XF_ACC_BIAS(1 + part);
-      XF_GEMM320(HEAD_TILES);
+      XF_GEMMCC(HEAD_TILES);
       XF_ROW_STORE(out_srd, p.ldout, row0, part * XC);
       xwait<0>();
       landed = issued;
     }
-    // ---------------- phase 4: v -> transposed through LDS -> v^T[b, c, l0 .. l0 + 128) ----------------
+    // ---------------- phase 4: v -> transposed through LDS -> v^T[b, c, l0 .. l0 + BM) ----------------
     XF_ACC_BIAS(3);
-    XF_GEMM320(HEAD_TILES);
-    xbarrier();  // all waves are done reading X: reuse it as the [320 channels][128 rows] transpose buffer
+    XF_GEMMCC(HEAD_TILES);
+    xbarrier();  // all waves are done reading X: reuse it as the [C channels][BM rows] transpose buffer
     {
       u16* ts = reinterpret_cast<u16*>(smem);
 #pragma unroll
@@ -776,7 +814,7 @@ __global__ __launch_bounds__(XNT) void xf_head_kernel(const XfParams p) {
       xbarrier();
       const int vt_so = (int)(((long long)b * p.vt_bs + l0) * 2);
       for (int q = tid; q < XC * (XBM / 8); q += XNT) {
-        const int n = q >> 4, mc = q & 15;
+        const int n = q / (XBM / 8), mc = q % (XBM / 8);
         const uint4 v = *reinterpret_cast<const uint4*>(ts + n * XBM + mc * 8);
         xst_u4(vt_srd, (int)((n * p.vt_ld + mc * 8) * 2) + vt_so, v);
       }
@@ -800,13 +838,65 @@ int xf_set_lds(KT kern) {
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS);
 }
 
+template <int CC>
+int xf_launch_tail(int dtype, int stop_after, int grid, hipStream_t s, const XfParams& p) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (xf_set_lds(&xf_tail_kernel<F16, 0, CC>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 0, CC>) != 0 ||
+        xf_set_lds(&xf_tail_kernel<F16, 1, CC>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 1, CC>) != 0 ||
+        xf_set_lds(&xf_tail_kernel<F16, 2, CC>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 3, CC>) != 0 ||
+        xf_set_lds(&xf_tail_kernel<F16, 4, CC>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 5, CC>) != 0) {
+      dbir_set_error("dbir_xf_tail: cannot reserve %d bytes of LDS", XF_LDS);
+      return DBIR_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  if (stop_after >= 99) {  // section timing (99) / ablations (103 - 105), f16 only, results meaningless
+    DBIR_CHECK_ARG(dtype == DBIR_F16, "dbir_xf_tail: the timing instantiations are f16 only");
+    if (stop_after == 99) hipLaunchKernelGGL((xf_tail_kernel<F16, 2, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else if (stop_after == 103) hipLaunchKernelGGL((xf_tail_kernel<F16, 3, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else if (stop_after == 104) hipLaunchKernelGGL((xf_tail_kernel<F16, 4, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else hipLaunchKernelGGL((xf_tail_kernel<F16, 5, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+  } else if (stop_after) {  // debug instantiation (tests): intermediate dumps
+    if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, 1, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else hipLaunchKernelGGL((xf_tail_kernel<BF16, 1, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+  } else {
+    if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, 0, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+    else hipLaunchKernelGGL((xf_tail_kernel<BF16, 0, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+  }
+  return DBIR_OK;
+}
+
+template <int CC>
+int xf_launch_head(int dtype, int grid, hipStream_t s, const XfParams& p) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (xf_set_lds(&xf_head_kernel<F16, CC>) != 0 || xf_set_lds(&xf_head_kernel<BF16, CC>) != 0) {
+      dbir_set_error("dbir_xf_head: cannot reserve %d bytes of LDS", XF_LDS);
+      return DBIR_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_head_kernel<F16, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+  else hipLaunchKernelGGL((xf_head_kernel<BF16, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+  return DBIR_OK;
+}
+
 }  // namespace
 
 void dbir_xf_set_variant(int v) { g_xf_variant = v; }
 
 extern "C" int dbir_xf_tile_bytes(void) { return TILE_BYTES; }
-extern "C" int dbir_xf_tail_tiles(void) { return TAIL_TILES; }
-extern "C" int dbir_xf_head_tiles(void) { return HEAD_TILES; }
+extern "C" int dbir_xf_tail_tiles(void) { return XfCfg<320>::TAIL_TILES; }
+extern "C" int dbir_xf_head_tiles(void) { return XfCfg<320>::HEAD_TILES; }
+// geometry of the fused kernels for inner width C (320 or 640): panel rows, tiles of the head / tail weight streams
+extern "C" int dbir_xf_geometry(int C, int* panel_rows, int* head_tiles, int* tail_tiles) {
+  DBIR_CHECK_ARG(C == 320 || C == 640, "dbir_xf_geometry: the fused transformer kernels are built for C = 320 and 640 (got %d)", C);
+  if (panel_rows) *panel_rows = C == 320 ? XfCfg<320>::BM : XfCfg<640>::BM;
+  if (head_tiles) *head_tiles = C == 320 ? XfCfg<320>::HEAD_TILES : XfCfg<640>::HEAD_TILES;
+  if (tail_tiles) *tail_tiles = C == 320 ? XfCfg<320>::TAIL_TILES : XfCfg<640>::TAIL_TILES;
+  return DBIR_OK;
+}
 
 extern "C" int dbir_xf_tail(int dtype, const void* attn_out, long long ldo, const void* h, long long ldh, const void* x,
                             long long ldx, void* out, long long ldout, int M, int L, int C, int pair_bs,
@@ -814,8 +904,10 @@ extern "C" int dbir_xf_tail(int dtype, const void* attn_out, long long ldo, cons
                             const void* vfrag, int Lk, float scale, int stop_after, void* stream) {
   DBIR_CHECK_ARG(attn_out && h && x && out && wstream && prm && kfrag && vfrag, "dbir_xf_tail: null pointer");
   DBIR_CHECK_ARG(dtype == DBIR_F16 || dtype == DBIR_BF16, "dbir_xf_tail: bad dtype %d", dtype);
-  DBIR_CHECK_ARG(C == XC, "dbir_xf_tail: built for C = %d (got %d)", XC, C);
-  DBIR_CHECK_ARG(M > 0 && L > 0 && L % XBM == 0 && M % L == 0, "dbir_xf_tail: M %d must be whole samples of L %d rows, L %% %d == 0", M, L, XBM);
+  DBIR_CHECK_ARG(C == 320 || C == 640, "dbir_xf_tail: built for C = 320 and 640 (got %d)", C);
+  const int BM = C == 320 ? XfCfg<320>::BM : XfCfg<640>::BM;
+  const int tiles = C == 320 ? XfCfg<320>::TAIL_TILES : XfCfg<640>::TAIL_TILES;
+  DBIR_CHECK_ARG(M > 0 && L > 0 && L % BM == 0 && M % L == 0, "dbir_xf_tail: M %d must be whole samples of L %d rows, L %% %d == 0", M, L, BM);
   DBIR_CHECK_ARG(pair_bs >= 0 && (pair_bs == 0 || (M / L) % (2 * pair_bs) == 0), "dbir_xf_tail: bad pair_bs %d for %d samples", pair_bs, M / L);
   DBIR_CHECK_ARG(ldo % 8 == 0 && ldh % 8 == 0 && ldx % 8 == 0 && ldout % 8 == 0 && ldo >= C && ldh >= C && ldx >= C && ldout >= C,
                  "dbir_xf_tail: row strides must be multiples of 8 and >= C");
@@ -823,7 +915,7 @@ extern "C" int dbir_xf_tail(int dtype, const void* attn_out, long long ldo, cons
                    reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(wstream) | reinterpret_cast<uintptr_t>(prm) |
                    reinterpret_cast<uintptr_t>(kfrag) | reinterpret_cast<uintptr_t>(vfrag)) & 15) == 0,
                  "dbir_xf_tail: pointers must be 16-byte aligned");
-  DBIR_CHECK_ARG(wstream_bytes >= (long long)TAIL_TILES * TILE_BYTES, "dbir_xf_tail: weight stream too short");
+  DBIR_CHECK_ARG(wstream_bytes >= (long long)tiles * TILE_BYTES, "dbir_xf_tail: weight stream too short");
   DBIR_CHECK_ARG(Lk > 0 && Lk <= XLKP, "dbir_xf_tail: context length %d > %d", Lk, XLKP);
   const long long src_rows = pair_bs ? M / 2 : M;
   DBIR_CHECK_ARG(((src_rows - 1) * ldo + C) * 2 < 0x7ffffe00LL && ((src_rows - 1) * ldh + C) * 2 < 0x7ffffe00LL &&
@@ -839,36 +931,14 @@ extern "C" int dbir_xf_tail(int dtype, const void* attn_out, long long ldo, cons
   p.wstream = wstream; p.prm = prm;
   p.kf = (const u16*)kfrag; p.vf = (const u16*)vfrag;
   p.Lk = Lk; p.c = scale * 1.4426950408889634f;
-  p.npanels = M / XBM;
+  p.npanels = M / BM;
   p.stop_after = stop_after;
   p.variant = g_xf_variant;
-  p.prm_row_bytes = XC * 4;
+  p.prm_row_bytes = C * 4;
   const int grid = xf_grid(p.npanels, &p.q, &p.gx);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (xf_set_lds(&xf_tail_kernel<F16, 0>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 0>) != 0 ||
-        xf_set_lds(&xf_tail_kernel<F16, 1>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 1>) != 0 ||
-        xf_set_lds(&xf_tail_kernel<F16, 2>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 3>) != 0 ||
-        xf_set_lds(&xf_tail_kernel<F16, 4>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 5>) != 0) {
-      dbir_set_error("dbir_xf_tail: cannot reserve %d bytes of LDS", XF_LDS);
-      return DBIR_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
-  if (stop_after >= 99) {  // section timing (99) / ablations (103 - 105), f16 only, results meaningless
-    DBIR_CHECK_ARG(dtype == DBIR_F16, "dbir_xf_tail: the timing instantiations are f16 only");
-    if (stop_after == 99) hipLaunchKernelGGL((xf_tail_kernel<F16, 2>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-    else if (stop_after == 103) hipLaunchKernelGGL((xf_tail_kernel<F16, 3>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-    else if (stop_after == 104) hipLaunchKernelGGL((xf_tail_kernel<F16, 4>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-    else hipLaunchKernelGGL((xf_tail_kernel<F16, 5>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-  } else if (stop_after) {  // debug instantiation (tests): intermediate dumps
-    if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, 1>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-    else hipLaunchKernelGGL((xf_tail_kernel<BF16, 1>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-  } else {
-    if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, 0>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-    else hipLaunchKernelGGL((xf_tail_kernel<BF16, 0>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-  }
+  const int rc = C == 320 ? xf_launch_tail<320>(dtype, stop_after, grid, s, p) : xf_launch_tail<640>(dtype, stop_after, grid, s, p);
+  if (rc != DBIR_OK) return rc;
   DBIR_CHECK_LAUNCH("dbir_xf_tail");
   return DBIR_OK;
 }
@@ -878,8 +948,10 @@ extern "C" int dbir_xf_head(int dtype, const void* x, long long ldx, const float
                             const void* wstream, long long wstream_bytes, const float* prm, void* stream) {
   DBIR_CHECK_ARG(x && gn_scale_shift && h && qk && vt && wstream && prm, "dbir_xf_head: null pointer");
   DBIR_CHECK_ARG(dtype == DBIR_F16 || dtype == DBIR_BF16, "dbir_xf_head: bad dtype %d", dtype);
-  DBIR_CHECK_ARG(C == XC, "dbir_xf_head: built for C = %d (got %d)", XC, C);
-  DBIR_CHECK_ARG(M > 0 && L > 0 && L % XBM == 0 && M % L == 0, "dbir_xf_head: M %d must be whole samples of L %d rows, L %% %d == 0", M, L, XBM);
+  DBIR_CHECK_ARG(C == 320 || C == 640, "dbir_xf_head: built for C = 320 and 640 (got %d)", C);
+  const int BM = C == 320 ? XfCfg<320>::BM : XfCfg<640>::BM;
+  const int tiles = C == 320 ? XfCfg<320>::HEAD_TILES : XfCfg<640>::HEAD_TILES;
+  DBIR_CHECK_ARG(M > 0 && L > 0 && L % BM == 0 && M % L == 0, "dbir_xf_head: M %d must be whole samples of L %d rows, L %% %d == 0", M, L, BM);
   DBIR_CHECK_ARG(ldx % 8 == 0 && ldh % 8 == 0 && ldqk % 8 == 0 && vt_ld % 8 == 0 && vt_bstride % 8 == 0 && ldx >= C && ldh >= C &&
                      ldqk >= 2 * C && vt_ld >= L,
                  "dbir_xf_head: bad strides");
@@ -887,7 +959,7 @@ extern "C" int dbir_xf_head(int dtype, const void* x, long long ldx, const float
                    reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(wstream) | reinterpret_cast<uintptr_t>(prm) |
                    reinterpret_cast<uintptr_t>(gn_scale_shift)) & 15) == 0,
                  "dbir_xf_head: pointers must be 16-byte aligned");
-  DBIR_CHECK_ARG(wstream_bytes >= (long long)HEAD_TILES * TILE_BYTES, "dbir_xf_head: weight stream too short");
+  DBIR_CHECK_ARG(wstream_bytes >= (long long)tiles * TILE_BYTES, "dbir_xf_head: weight stream too short");
   DBIR_CHECK_ARG(((long long)(M - 1) * ldx + C) * 2 < 0x7ffffe00LL && ((long long)(M - 1) * ldh + C) * 2 < 0x7ffffe00LL &&
                      ((long long)(M - 1) * ldqk + 2 * C) * 2 < 0x7ffffe00LL &&
                      ((long long)(M / L - 1) * vt_bstride + (long long)(C - 1) * vt_ld + L) * 2 < 0x7ffffe00LL,
@@ -901,21 +973,13 @@ extern "C" int dbir_xf_head(int dtype, const void* x, long long ldx, const float
   p.ab = gn_scale_shift;
   p.M = M; p.L = L;
   p.wstream = wstream; p.prm = prm;
-  p.npanels = M / XBM;
+  p.npanels = M / BM;
   p.variant = g_xf_variant;
-  p.prm_row_bytes = XC * 4;
+  p.prm_row_bytes = C * 4;
   const int grid = xf_grid(p.npanels, &p.q, &p.gx);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (xf_set_lds(&xf_head_kernel<F16>) != 0 || xf_set_lds(&xf_head_kernel<BF16>) != 0) {
-      dbir_set_error("dbir_xf_head: cannot reserve %d bytes of LDS", XF_LDS);
-      return DBIR_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
-  if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_head_kernel<F16>), dim3(grid), dim3(XNT), XF_LDS, s, p);
-  else hipLaunchKernelGGL((xf_head_kernel<BF16>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+  const int rc = C == 320 ? xf_launch_head<320>(dtype, grid, s, p) : xf_launch_head<640>(dtype, grid, s, p);
+  if (rc != DBIR_OK) return rc;
   DBIR_CHECK_LAUNCH("dbir_xf_head");
   return DBIR_OK;
 }

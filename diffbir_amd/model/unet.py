@@ -38,6 +38,8 @@ SHARE_CFG_PREFIX = os.environ.get("DBIR_SHARE_CFG_PREFIX", "1") != "0"
 # run the transformer blocks of the 64x64 level (C = 320) on the fused row-panel kernels (csrc/xformer.hip):
 # groupnorm_affine -> xf_head -> self-attention -> xf_tail instead of 16 launches (A/B switch: DBIR_FUSED_XF=0)
 FUSED_XF = os.environ.get("DBIR_FUSED_XF", "1") != "0"
+# widths whose blocks are packed for the fused kernels: DBIR_FUSED_XF = 1 (default: 320 and 640), 0 (none), 320 or 640 (A/B)
+FUSED_XF_WIDTHS = {"0": (), "1": (320, 640), "320": (320,), "640": (640,)}.get(os.environ.get("DBIR_FUSED_XF", "1"), (320, 640))
 # GroupNorm statistics from the producing GEMM's epilogue (column sums per output tile, ops.GnPartials) instead of a
 # statistics pass over the tensor (A/B switch: DBIR_GN_EPILOGUE_STATS=0)
 GN_EPI_STATS = os.environ.get("DBIR_GN_EPILOGUE_STATS", "1") != "0"
@@ -122,7 +124,7 @@ class _DiffusionNet(NativeModule):
                                self._device)
         a.ff2 = self._pk_lin(f"{q}.ff.net.2")
         a.xf = None
-        if ch == 320 and FUSED_XF:  # fused row-panel kernels (the per-launch weights above stay for other sequence lengths)
+        if ch in FUSED_XF_WIDTHS and FUSED_XF:  # fused row-panel kernels (the per-launch weights above stay for other shapes)
             names = {"proj_in": f"{p}.proj_in", "norm1": f"{q}.norm1", "q1": f"{q}.attn1.to_q", "k1": f"{q}.attn1.to_k",
                      "v1": f"{q}.attn1.to_v", "out1": f"{q}.attn1.to_out.0", "norm2": f"{q}.norm2", "q2": f"{q}.attn2.to_q",
                      "out2": f"{q}.attn2.to_out.0", "norm3": f"{q}.norm3", "ff1": f"{q}.ff.net.0.proj", "ff2": f"{q}.ff.net.2",
@@ -233,7 +235,7 @@ class _DiffusionNet(NativeModule):
         L = H * W
         scale = self.plan.head_dim ** -0.5
         ckv = ctx_kv[a.ctx_idx]
-        if a.xf is not None and len(ckv) == 4 and ops.xf_supported(C, L, ckv[0].shape[1]):
+        if a.xf is not None and len(ckv) == 4 and ops.xf_supported(C, L, ckv[0].shape[1], B * L * (2 if pair is not None else 1)):
             ab = ops.groupnorm_affine(x, a.gn[0], a.gn[1], 1e-6, stats=x_stats)
             h, qk, vt = ops.xf_head(x, ab, a.xf, L)
             o = torch.empty((B, L, C), dtype=x.dtype, device=x.device)

@@ -1,11 +1,11 @@
 """Host side of the fused transformer-block kernels (csrc/xformer.hip): weight-stream packing and the op wrappers.
 
-A SpatialTransformer of the 64x64 latent level (C = 320; reference attention.py:334-353 around
-BasicTransformerBlock._forward, attention.py:265-274) runs as
+A SpatialTransformer of the 64x64 latent level (C = 320) or the 32x32 level (C = 640; reference attention.py:334-353
+around BasicTransformerBlock._forward, attention.py:265-274) runs as
 
     groupnorm_affine -> xf_head -> attention (self) -> xf_tail
 
-The kernels keep a 128-row activation panel in LDS and stream ALL weights of the block through a 3-slot LDS ring as
+The kernels keep a 128-row (C = 320) / 64-row (C = 640) activation panel in LDS and stream ALL weights of the block through a 3-slot LDS ring as
 one flat sequence of tiles; this module lays that sequence out.  A tile is 20 "fragment pieces" of 1 KB — piece
 (block j, k-step s) holds rows [32 j, 32 j + 32) x columns [16 s, 16 s + 16) of a weight matrix [N, K] in the order an
 MFMA 32x32x16 operand fragment is read: lane = 32 * hi + lq owns row 32 j + lq, columns 16 s + 8 hi .. + 8 — followed by
@@ -15,12 +15,17 @@ The LayerNorm affine maps are folded into the GEMMs that consume the normalised 
 xhat (W diag(gamma))^T + W beta: to_q / to_k / to_v (norm1), attn2.to_q (norm2) and ff.net.0.proj (norm3) are stored
 column-scaled, the W beta rows are the accumulators' initial values (parameter rows / the chunk's side data).
 
+  (C = 320)
   head: proj_in, to_q, to_k, to_v                      10 tiles each: K tile kt = pieces [k-step 2 kt + ksl][block j]
   tail: attn1.to_out, attn2.to_q, attn2.to_out         10 tiles each, as above
         20 feed-forward chunks of 64 hidden units c:   4 tiles of ff.net.0.proj rows (value, gate blocks interleaved per
                                                        32: blocks 4c .. 4c+3), tile i = pieces [k-step 5 i + ksl][block];
                                                        2 tiles of ff.net.2 columns [64 c, 64 c + 64): [k-step 2 i + ksl][j]
         proj_out                                       10 tiles
+
+  (C = 640: 20 column blocks, so a tile of an N = C GEMM is ONE k-step, 40 tiles per GEMM; a feed-forward chunk is 128
+  hidden units = two runs of 8 GEGLU-projection tiles in the C = 320 format (run s = hidden blocks 4c + 2s, 4c + 2s + 1),
+  then 8 one-k-step tiles of ff.net.2 columns [128 c, 128 c + 128).)  `geometry(C)` has the numbers.
 """
 import ctypes
 from dataclasses import dataclass
@@ -32,10 +37,46 @@ from . import native
 
 T = torch.Tensor
 XC = 320
+WIDTHS = (320, 640)
 TILE_W, TILE_AUX = 20480, 512
 TILE_BYTES = TILE_W + TILE_AUX
-HEAD_TILES, TAIL_TILES = 40, 160
+HEAD_TILES, TAIL_TILES = 40, 160            # C = 320
 LK_PAD = 96
+MIN_PANELS_640 = 160   # C = 640: 64-row panels, one per CU — below ~160 panels the per-launch kernels win (idle CUs)
+
+
+@dataclass(frozen=True)
+class Geometry:
+    """csrc/xformer.hip XfCfg<C>."""
+    C: int
+    WN: int          # column groups of 160 (waves per row block)
+    WM: int          # row blocks of 32
+    BM: int          # panel rows
+    NB: int          # column blocks of an N = C GEMM
+    GNKS: int        # k-steps per tile of an N = C GEMM
+    GNT: int         # tiles of a C x C GEMM
+    NSUB: int        # GEGLU-projection runs per feed-forward chunk
+    CHH: int         # hidden units per chunk
+    CH: int          # chunks
+    F1T: int         # tiles per GEGLU-projection run
+    GKST: int        # k-steps of a chunk
+    F2T: int         # tiles of a chunk's output projection
+    head_tiles: int
+    tail_tiles: int
+
+
+def geometry(C: int) -> Geometry:
+    assert C in WIDTHS, f"fused transformer kernels are built for C in {WIDTHS}"
+    WN = C // 160
+    WM = 8 // WN
+    NB, KS = C // 32, C // 16
+    GNKS = 20 // NB
+    GNT = KS // GNKS
+    NSUB, CHH = WN // 2, 32 * WN
+    CH, F1T, GKST = 4 * C // CHH, KS // 5, CHH // 16
+    F2T = GKST // GNKS
+    return Geometry(C, WN, WM, 32 * WM, NB, GNKS, GNT, NSUB, CHH, CH, F1T, GKST, F2T, 4 * GNT,
+                    4 * GNT + CH * (NSUB * F1T + F2T))
 
 
 @dataclass
@@ -55,11 +96,13 @@ def _pieces(w: T) -> T:
     return w.reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(N // 32, K // 16, 64, 8).contiguous()
 
 
-def _tiles_n320(w: T) -> T:
-    """[320, K] -> [K/32 tiles, 20 pieces, 64, 8], piece index = ksl * 10 + j."""
-    p = _pieces(w)                                   # [10, K/16, 64, 8]
-    nkt = p.shape[1] // 2
-    return p.reshape(10, nkt, 2, 64, 8).permute(1, 2, 0, 3, 4).reshape(nkt, 20, 64, 8)
+def _tiles_nc(w: T) -> T:
+    """[C, K] -> [K / (16 GNKS) tiles, 20 pieces, 64, 8], piece index = ksl * (C / 32) + j."""
+    p = _pieces(w)                                   # [C/32, K/16, 64, 8]
+    nb = p.shape[0]
+    gnks = 20 // nb
+    nkt = p.shape[1] // gnks
+    return p.reshape(nb, nkt, gnks, 64, 8).permute(1, 2, 0, 3, 4).reshape(nkt, 20, 64, 8)
 
 
 def _geglu_interleave(w: T, b: T) -> Tuple[T, T]:
@@ -86,7 +129,8 @@ def pack_block(w: Dict[str, T], dtype, device) -> XfBlock:
     ff2.{w,b}, proj_out.{w,b}."""
     g = {k: v.detach().float().cpu().reshape(v.shape[0], -1) if v.dim() > 1 else v.detach().float().cpu() for k, v in w.items()}
     C = g["proj_in.w"].shape[0]
-    assert C == XC and g["ff2.w"].shape == (C, 4 * C), "fused transformer kernels are built for C = 320"
+    geo = geometry(C)
+    assert g["ff2.w"].shape == (C, 4 * C)
     # LayerNorm affine maps folded into the consuming GEMMs: (xhat * gamma + beta) W^T = xhat (W diag(gamma))^T + W beta
     fold = lambda wn, nn: (g[wn] * g[nn + ".w"][None, :], g[wn] @ g[nn + ".b"])  # noqa: E731
     (q1w, q1b), (k1w, k1b), (v1w, v1b) = fold("q1.w", "norm1"), fold("k1.w", "norm1"), fold("v1.w", "norm1")
@@ -100,22 +144,25 @@ def pack_block(w: Dict[str, T], dtype, device) -> XfBlock:
         e = torch.empty((0, TILE_BYTES), dtype=torch.uint8, device=device)
         return XfBlock(e, head_prm, e, tail_prm, C // 64, logical)
     h = lambda name: g[name].to(dtype)  # noqa: E731  (weights are rounded to the 16-bit compute type once, here)
-    head = torch.cat([_tiles_n320(t.to(dtype)) for t in (g["proj_in.w"], q1w, k1w, v1w)])
+    head = torch.cat([_tiles_nc(t.to(dtype)) for t in (g["proj_in.w"], q1w, k1w, v1w)])
     w1, b1 = _geglu_interleave(ff1w, ff1b)
-    p1 = _pieces(w1.to(dtype))                      # [80 blocks, 20 k-steps, 64, 8]
-    p2 = _pieces(h("ff2.w"))                        # [10 blocks, 80 k-steps, 64, 8]
+    p1 = _pieces(w1.to(dtype))                      # [8 C / 32 blocks, C / 16 k-steps, 64, 8]
+    p2 = _pieces(h("ff2.w"))                        # [C / 32 blocks, 4 C / 16 k-steps, 64, 8]
     ff_tiles, ff_aux = [], []
-    for c in range(4 * C // 64):
-        for i in range(4):                          # piece = ksl * 4 + block
-            ff_tiles.append(p1[4 * c:4 * c + 4, 5 * i:5 * i + 5].permute(1, 0, 2, 3).reshape(20, 64, 8))
-            ff_aux.append(b1[128 * c:128 * c + 128])
-        for i in range(2):                          # piece = ksl * 10 + j
-            ff_tiles.append(p2[:, 4 * c + 2 * i:4 * c + 2 * i + 2].permute(1, 0, 2, 3).reshape(20, 64, 8))
+    for c in range(geo.CH):
+        for sub in range(geo.NSUB):                 # run = hidden blocks 2 sc, 2 sc + 1 (value / gate interleaved: 4 blocks)
+            sc = c * geo.NSUB + sub
+            for i in range(geo.F1T):                # piece = ksl * 4 + block
+                ff_tiles.append(p1[4 * sc:4 * sc + 4, 5 * i:5 * i + 5].permute(1, 0, 2, 3).reshape(20, 64, 8))
+                ff_aux.append(b1[128 * sc:128 * sc + 128])
+        for i in range(geo.F2T):                    # piece = ksl * (C / 32) + j
+            k0 = geo.GKST * c + geo.GNKS * i
+            ff_tiles.append(p2[:, k0:k0 + geo.GNKS].permute(1, 0, 2, 3).reshape(20, 64, 8))
             ff_aux.append(torch.zeros(128))
-    tail = torch.cat([_tiles_n320(h("out1.w")), _tiles_n320(q2w.to(dtype)), _tiles_n320(h("out2.w")),
-                      torch.stack(ff_tiles), _tiles_n320(h("proj_out.w"))])
-    tail_aux = torch.cat([torch.zeros(30, 128), torch.stack(ff_aux), torch.zeros(10, 128)])
-    assert head.shape[0] == HEAD_TILES and tail.shape[0] == TAIL_TILES
+    tail = torch.cat([_tiles_nc(h("out1.w")), _tiles_nc(q2w.to(dtype)), _tiles_nc(h("out2.w")),
+                      torch.stack(ff_tiles), _tiles_nc(h("proj_out.w"))])
+    tail_aux = torch.cat([torch.zeros(3 * geo.GNT, 128), torch.stack(ff_aux), torch.zeros(geo.GNT, 128)])
+    assert head.shape[0] == geo.head_tiles and tail.shape[0] == geo.tail_tiles
     return XfBlock(_finish_stream(head, None, device), head_prm, _finish_stream(tail, tail_aux, device), tail_prm,
                    C // 64, logical)
 
@@ -172,8 +219,16 @@ def _rows_ld(t: T) -> Tuple[int, int]:
     return n, ld
 
 
-def supported(C: int, L: int, Lk: int) -> bool:
-    return C == XC and L % 128 == 0 and 0 < Lk <= LK_PAD
+def supported(C: int, L: int, Lk: int, M: Optional[int] = None) -> bool:
+    """Can (and should) a block of inner width C with L rows per sample (M rows in all) run on the fused kernels?"""
+    if C not in WIDTHS or not 0 < Lk <= LK_PAD:
+        return False
+    bm = geometry(C).BM
+    if L % bm:
+        return False
+    if C == 640 and M is not None and M // bm < MIN_PANELS_640:
+        return False
+    return True
 
 
 def groupnorm_affine(x: T, gamma: T, beta: T, eps: float, groups: int = 32) -> T:

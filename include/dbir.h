@@ -194,18 +194,22 @@ int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, long long l
 int dbir_softmax_rows(int dtype, void* x, long long ld, long long rows, int L, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Fused transformer-block kernels for the 64x64 latent level, C = 320 (csrc/xformer.hip).  One SpatialTransformer
+ * Fused transformer-block kernels for the 64x64 latent level (C = 320) and the 32x32 level (C = 640), csrc/xformer.hip.
+ * One SpatialTransformer
  * (reference attention.py:334-353 around BasicTransformerBlock._forward attention.py:265-274) becomes
  *   dbir_groupnorm_affine -> dbir_xf_head -> dbir_attention (self) -> dbir_xf_tail
- * instead of 16 launches; the activation is processed in 128-row panels that stay in LDS across the chained GEMMs /
- * LayerNorms / text cross-attention / GEGLU feed-forward, only the weights stream in.
+ * instead of 16 launches; the activation is processed in 128-row (C = 320) / 64-row (C = 640) panels that stay in LDS
+ * across the chained GEMMs / LayerNorms / text cross-attention / GEGLU feed-forward, only the weights stream in.
+ * dbir_xf_geometry(C, &panel_rows, &head_tiles, &tail_tiles): panel height and stream lengths for C = 320 / 640
+ * (dbir_xf_head_tiles() / dbir_xf_tail_tiles() are the C = 320 values).  At C = 640 a panel occupies a whole CU, so the
+ * fused form pays from ~160 panels (M >= 10240 rows) on; below that launch the per-operator kernels.
  * Weights: ONE packed stream per kernel (diffbir_amd/xformer.py: tiles of dbir_xf_tile_bytes() bytes = 20 MFMA fragment
  * pieces of [32 rows][16 k] in LDS order + 512 B of f32 side data), dbir_xf_head_tiles() / dbir_xf_tail_tiles() tiles.
  * prm: f32 rows of C floats — head: proj_in bias, W beta1 for to_q / to_k / to_v; tail: attn1.to_out bias, Wq2 beta2,
  * attn2.to_out bias, ff.net.2 bias, proj_out bias (the LayerNorm affine maps are folded into the consuming weights).
  *
  * dbir_xf_head: x [M, C] (block input) -> h = proj_in(x * a + s) [M, C]; n = LayerNorm1(h); qk [M, 2C] = n Wq^T | n Wk^T;
- *   vt[b, c, l] = (n Wv^T)[b * L + l, c]  (attention.py:344-345, 266, 189-200 projections).  M = B * L, L % 128 == 0.
+ *   vt[b, c, l] = (n Wv^T)[b * L + l, c]  (attention.py:344-345, 266, 189-200 projections).  M = B * L, L % panel_rows == 0.
  * dbir_xf_tail: attn [Ms, C] (self-attention output), h [Ms, C], x [Ms, C] ->
  *   h1 = attn Wo1^T + b + h; a = softmax(LN2(h1) Wq^T K_ctx^T * scale) V_ctx; h2 = a Wo2^T + b + h1;
  *   h3 = (u * gelu(g)) W2^T + b + h2 with u | g = LN3(h2) W1^T + b; out [M, C] = h3 Wpo^T + b + x
@@ -218,6 +222,7 @@ int dbir_softmax_rows(int dtype, void* x, long long ld, long long rows, int L, v
 int dbir_xf_tile_bytes(void);
 int dbir_xf_head_tiles(void);
 int dbir_xf_tail_tiles(void);
+int dbir_xf_geometry(int C, int* panel_rows, int* head_tiles, int* tail_tiles);
 int dbir_xf_head(int dtype, const void* x, long long ldx, const float* gn_scale_shift, void* h, long long ldh, void* qk,
                  long long ldqk, void* vt, long long vt_ld, long long vt_bstride, int M, int L, int C, const void* wstream,
                  long long wstream_bytes, const float* prm, void* stream);

@@ -645,10 +645,9 @@ def test_epilogue_group_norm_statistics(tile, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ fused transformer block
-def _xf_weights(seed=0, gain=1.0):
-    """Random weights of one C = 320 transformer block (f32, CPU), by the short names of xformer.pack_block."""
+def _xf_weights(seed=0, gain=1.0, C=320):
+    """Random weights of one transformer block of inner width C (f32, CPU), by the short names of xformer.pack_block."""
     g = torch.Generator().manual_seed(seed)
-    C = 320
     r = lambda *shape: torch.randn(*shape, generator=g)  # noqa: E731
     w = {}
     for n in ("proj_in", "out1", "out2", "proj_out"):
@@ -666,13 +665,13 @@ XF_STOPS = [(11, "h1"), (1, "LN2"), (2, "q"), (3, "cross-attn"), (14, "h2"), (4,
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,L", [(2, 256), (9, 4096)])
-def test_xf_tail(B, L, dtype):
+@pytest.mark.parametrize("C,B,L", [(320, 2, 256), (320, 9, 4096), (640, 2, 192), (640, 18, 1024)])
+def test_xf_tail(C, B, L, dtype):
     """Fused transformer tail (xformer.hip) against the f32 statement on the UNPACKED weights, phase by phase (debug dumps
     of every intermediate: residual stream, LayerNorm outputs, q, text cross-attention, feed-forward) and end to end;
-    (9, 4096) = 288 panels: workgroups walk several panels (weight stream wraps, panel hand-over)."""
-    C, heads, Lk = 320, 5, 77
-    blk = ops.pack_xf_block(_xf_weights(), dtype, DEV)
+    (320, 9, 4096) / (640, 18, 1024) = 288 panels: workgroups walk several panels (weight stream wraps, panel hand-over)."""
+    heads, Lk = C // 64, 77
+    blk = ops.pack_xf_block(_xf_weights(C=C), dtype, DEV)
     attn, h = rnd(B * L, C, dtype=dtype, seed=1), rnd(B * L, C, dtype=dtype, seed=2)
     x = rnd(B, L // 64, 64, C, dtype=dtype, seed=3)
     k, vt = rnd(B, Lk, C, dtype=dtype, seed=4), rnd(B, C, 80, dtype=dtype, seed=5)
@@ -711,11 +710,10 @@ def test_xf_tail_pairs_and_strided_output(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,L", [(2, 128), (5, 4096), (9, 4096)])
-def test_xf_head(B, L, dtype):
+@pytest.mark.parametrize("C,B,L", [(320, 2, 128), (320, 5, 4096), (320, 9, 4096), (640, 3, 64), (640, 18, 1024)])
+def test_xf_head(C, B, L, dtype):
     """GroupNorm statistics folded to an affine map, then the fused head: h, q | k and v^T against the f32 statement."""
-    C = 320
-    blk = ops.pack_xf_block(_xf_weights(seed=1), dtype, DEV)
+    blk = ops.pack_xf_block(_xf_weights(seed=1, C=C), dtype, DEV)
     x = (rnd(B, L // 64, 64, C, dtype=torch.float32, seed=7) * 1.5 + 0.3).to(dtype)
     gam, bet = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=8), 0.1 * rnd(C, dtype=torch.float32, seed=9)
     ab = ops.groupnorm_affine(x, gam, bet, 1e-6)
@@ -734,13 +732,14 @@ def test_xf_head(B, L, dtype):
     check("groupnorm_affine == groupnorm", aff, gn, dtype)
 
 
-def test_xf_fp16_range_stress():
+@pytest.mark.parametrize("C", [320, 640])
+def test_xf_fp16_range_stress(C):
     """SD-like activation statistics in fp16: a residual stream with a few outlier channels of
     magnitude ~3e3 (LayerNorm statistics dominated by them: two-pass variance), GEGLU pre-activations of O(1e2) whose
     products reach ~1e4 (fp16 max 65504), attention logits of O(1e2).  The fused kernels must stay finite and agree with
     the f32 statement rounded at the same points; the per-launch kernels are held to the same inputs."""
-    dtype, C, heads, Lk, B, L = torch.float16, 320, 5, 77, 2, 512
-    w = _xf_weights(seed=7, gain=2.5)
+    dtype, heads, Lk, B, L = torch.float16, C // 64, 77, 2, 512
+    w = _xf_weights(seed=7, gain=2.5, C=C)
     w["ff1.b"] = w["ff1.b"] * 20
     blk = ops.pack_xf_block(w, dtype, DEV)
     g = torch.Generator().manual_seed(11)
@@ -762,8 +761,9 @@ def test_xf_fp16_range_stress():
     pw1 = ops.pack_geglu(w["ff1.w"], w["ff1.b"], dtype, DEV)
     h2 = emu.xf_tail(attn, h, x, blk, ek, ev, Lk, 0.125, L, stop_after=14).reshape(-1, C)
     n3a = emu._ln(h2.float(), w["norm3.w"].to(DEV), w["norm3.b"].to(DEV)).to(dtype)
-    gg = ops.linear(n3a, pw1)
-    u = n3a.float() @ w["ff1.w"].to(DEV).to(dtype).float().t() + w["ff1.b"].to(DEV)
+    n3s = (n3a.float() * 12.0).to(dtype)          # pre-activations of O(1e2): products of value and gate reach ~1e4
+    gg = ops.linear(n3s, pw1)
+    u = n3s.float() @ w["ff1.w"].to(DEV).to(dtype).float().t() + w["ff1.b"].to(DEV)
     ref_g = (u[:, : 4 * C] * torch.nn.functional.gelu(u[:, 4 * C:])).to(dtype)
     assert torch.isfinite(ref_g.float()).all() and ref_g.float().abs().max() > 2e3 and n3.numel() == n3a.numel()
     check(f"GEGLU epilogue stress (|ref| max {ref_g.float().abs().max().item():.0f})", gg, ref_g, dtype, scale=2.0)
@@ -779,8 +779,10 @@ def test_xf_rejects_unsupported():
     kf, vf = ops.pack_context_frags(k, vt, 77, 5)
     with pytest.raises(Exception):   # L = 192 is not a multiple of the 128-row panel
         ops.xf_tail(attn, h, attn.reshape(1, 192, 320), blk, kf, vf, 77, 0.125, 192)
-    assert not ops.xf_supported(640, 1024, 77) and not ops.xf_supported(320, 192, 77) and not ops.xf_supported(320, 4096, 200)
-    assert ops.xf_supported(320, 4096, 77)
+    assert not ops.xf_supported(1280, 256, 77) and not ops.xf_supported(320, 192, 77) and not ops.xf_supported(320, 4096, 200)
+    assert ops.xf_supported(320, 4096, 77) and ops.xf_supported(640, 1024, 77) and ops.xf_supported(640, 1024, 77, 16 * 1024)
+    assert not ops.xf_supported(640, 1024, 77, 4 * 1024)      # 64 panels of 64 rows: most CUs idle -> per-launch kernels
+    assert not ops.xf_supported(640, 96, 77)
 
 
 # ------------------------------------------------------------------------------------------------ attention

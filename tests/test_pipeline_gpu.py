@@ -312,7 +312,10 @@ def test_full_config_batch_independence_and_fused_blocks(full_engine):
     # (2) same weights, fused blocks off: every transformer block of the 64x64 level through the per-launch kernels
     layers = [a for net in (cldm.unet, cldm.controlnet) for a in net._attn_layers]
     saved = [a.xf for a in layers]
-    assert sum(x is not None for x in saved) == 7, "the 5 + 2 C = 320 blocks of UNet + ControlNet run fused by default"
+    from diffbir_amd.model import unet as unet_mod
+    n320 = sum(x is not None and a.ch == 320 for a, x in zip(layers, saved))
+    assert n320 == (7 if 320 in unet_mod.FUSED_XF_WIDTHS else 0), "the 5 + 2 C = 320 blocks of UNet + ControlNet are packed for the fused kernels"
+    assert sum(x is not None for x in saved) == 7 * len(unet_mod.FUSED_XF_WIDTHS)   # (+ the 5 + 2 blocks of the 32x32 level)
     try:
         for a in layers:
             a.xf = None

@@ -13,10 +13,7 @@ from diffbir_amd import configs, xformer
 from diffbir_amd.utils.synth import synth_state_dict
 from tests import emu_ops
 
-C = 320
-
-
-def _rand_block(seed=0, scale=1.0):
+def _rand_block(C, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g) * scale  # noqa: E731
     w = {}
@@ -38,68 +35,91 @@ def _tile(stream, t):
     return pieces, aux
 
 
-def _read_gemm320(stream, t0):
-    """What the kernel's XF_GEMM320 multiplies: W[n][k] for n < 320, k < 320 from tiles t0 .. t0 + 9."""
+# What the kernels read, restated from csrc/xformer.hip with its own constants (NOT through xformer.geometry):
+#   wave (wm, wn) owns rows [32 wm, +32) x columns [160 wn, +160) = blocks 5 wn .. 5 wn + 4;  WN = C / 160
+#   XF_GEMMCC: GNT tiles of GNKS k-steps; W fragment of block j, k-step ks of tile i: piece ks * (C / 32) + j
+#   GEGLU run (sub s of chunk c): F1T tiles of 5 k-steps, piece ks * 4 + 2 (wn & 1) + {0: value, 1: gate}, for the waves
+#     with wn / 2 == s; hidden block of wave wn in chunk c = (C / 160) c + wn
+#   feed-forward output: F2T tiles of GNKS k-steps of the chunk's GKST = 2 WN k-steps, piece ks * (C / 32) + j
+KCONST = {320: dict(WN=2, GNKS=2, GNT=10, NSUB=1, F1T=4, GKST=4, F2T=2, HEAD=40, TAIL=160),
+          640: dict(WN=4, GNKS=1, GNT=40, NSUB=2, F1T=8, GKST=8, F2T=8, HEAD=160, TAIL=640)}
+
+
+def _read_gemm(stream, t0, C):
+    """What XF_GEMMCC multiplies: W[n][k] for n < C, k < C from tiles t0 .. t0 + GNT - 1."""
+    k = KCONST[C]
     W = np.zeros((C, C), np.float16)
-    for kt in range(10):
+    for kt in range(k["GNT"]):
         pieces, _ = _tile(stream, t0 + kt)
-        for ksl in range(2):
-            for wn in range(2):
+        for ksl in range(k["GNKS"]):
+            for wn in range(k["WN"]):
                 for jl in range(5):
-                    frag = pieces[ksl * 10 + 5 * wn + jl]            # tbase + (ks * PSTR + WFIRST + jl) * 1024
+                    frag = pieces[ksl * (C // 32) + 5 * wn + jl]       # tbase + (ks * PSTR + WFIRST + jl) * 1024
                     for lane in range(64):
                         lq, hi = lane & 31, lane >> 5
-                        W[32 * (5 * wn + jl) + lq, 32 * kt + 16 * ksl + 8 * hi:][:8] = frag[lane]
+                        W[32 * (5 * wn + jl) + lq, 16 * (k["GNKS"] * kt + ksl) + 8 * hi:][:8] = frag[lane]
     return W
 
 
-def test_weight_stream_is_what_the_kernel_reads():
-    w = _rand_block()
+@pytest.mark.parametrize("C", [320, 640])
+def test_weight_stream_is_what_the_kernel_reads(C):
+    k = KCONST[C]
+    w = _rand_block(C)
     blk = xformer.pack_block(w, torch.float16, torch.device("cpu"))
-    assert tuple(blk.head_stream.shape) == (xformer.HEAD_TILES, xformer.TILE_BYTES)
-    assert tuple(blk.tail_stream.shape) == (xformer.TAIL_TILES, xformer.TILE_BYTES)
+    assert tuple(blk.head_stream.shape) == (k["HEAD"], xformer.TILE_BYTES)
+    assert tuple(blk.tail_stream.shape) == (k["TAIL"], xformer.TILE_BYTES)
+    geo = xformer.geometry(C)
+    assert (geo.WN, geo.GNKS, geo.GNT, geo.NSUB, geo.F1T, geo.GKST, geo.F2T, geo.head_tiles, geo.tail_tiles) == \
+        tuple(k[n] for n in ("WN", "GNKS", "GNT", "NSUB", "F1T", "GKST", "F2T", "HEAD", "TAIL"))
+    assert geo.BM * C * 2 == 81920 and geo.CH == 20
     h16 = lambda n: w[n].half().numpy()  # noqa: E731
     # LayerNorm affine maps are folded into the consuming weights: W diag(gamma), bias W beta
     fw = lambda n, ln: (w[n] * w[ln + ".w"][None, :]).half().numpy()  # noqa: E731
     fb = lambda n, ln: (w[n] @ w[ln + ".b"]).numpy()                   # noqa: E731
+    G = k["GNT"]
     for i, exp in enumerate((h16("proj_in.w"), fw("q1.w", "norm1"), fw("k1.w", "norm1"), fw("v1.w", "norm1"))):
-        assert np.array_equal(_read_gemm320(blk.head_stream, 10 * i), exp), i
-    for t0, exp in ((0, h16("out1.w")), (10, fw("q2.w", "norm2")), (20, h16("out2.w")), (150, h16("proj_out.w"))):
-        assert np.array_equal(_read_gemm320(blk.tail_stream, t0), exp), t0
-    # feed-forward: chunk c = hidden units [64 c, 64 c + 64); wave column half wn owns hidden block 2 c + wn
+        assert np.array_equal(_read_gemm(blk.head_stream, G * i, C), exp), i
+    per_chunk = k["NSUB"] * k["F1T"] + k["F2T"]
+    for t0, exp in ((0, h16("out1.w")), (G, fw("q2.w", "norm2")), (2 * G, h16("out2.w")),
+                    (3 * G + 20 * per_chunk, h16("proj_out.w"))):
+        assert np.array_equal(_read_gemm(blk.tail_stream, t0, C), exp), t0
+    # feed-forward: chunk c = hidden units [32 WN c, +32 WN); wave column group wn owns hidden block WN c + wn
     w1, b1, w2 = fw("ff1.w", "norm3"), (w["ff1.b"] + w["ff1.w"] @ w["norm3.b"]).numpy(), h16("ff2.w")
+    WN = k["WN"]
     for c in (0, 7, 19):
-        t0 = 30 + 6 * c
-        val = np.zeros((2, 32, C), np.float16)
-        gate = np.zeros((2, 32, C), np.float16)
-        for i in range(4):                                   # XF_TILE(5, 2, 4, ..., 2 * wn, gacc)
-            pieces, aux = _tile(blk.tail_stream, t0 + i)
-            for ksl in range(5):
-                for wn in range(2):
-                    for blkid, dst in ((0, val), (1, gate)):
-                        frag = pieces[ksl * 4 + 2 * wn + blkid]
-                        for lane in range(64):
-                            lq, hi = lane & 31, lane >> 5
-                            dst[wn, lq, 16 * (5 * i + ksl) + 8 * hi:][:8] = frag[lane]
-            if i == 0:                                       # bias: aux[wn * 64 + blk * 32 + col]
-                for wn in range(2):
-                    hb = 2 * c + wn
-                    assert np.array_equal(aux[wn * 64:wn * 64 + 32], b1[32 * hb:32 * hb + 32])
-                    assert np.array_equal(aux[wn * 64 + 32:wn * 64 + 64], b1[4 * C + 32 * hb:4 * C + 32 * hb + 32])
-        for wn in range(2):
-            hb = 2 * c + wn
+        t0 = 3 * G + per_chunk * c
+        val = np.zeros((WN, 32, C), np.float16)
+        gate = np.zeros((WN, 32, C), np.float16)
+        for sub in range(k["NSUB"]):
+            for i in range(k["F1T"]):                        # XF_RUN_BODY(F1T, 5, 2, 4, ..., 2 * (wn & 1), gacc)
+                pieces, aux = _tile(blk.tail_stream, t0 + sub * k["F1T"] + i)
+                for ksl in range(5):
+                    for wl in range(2):
+                        wn = 2 * sub + wl
+                        for blkid, dst in ((0, val), (1, gate)):
+                            frag = pieces[ksl * 4 + 2 * wl + blkid]
+                            for lane in range(64):
+                                lq, hi = lane & 31, lane >> 5
+                                dst[wn, lq, 16 * (5 * i + ksl) + 8 * hi:][:8] = frag[lane]
+                if i == 0:                                   # bias: aux[wl * 64 + blk * 32 + col]
+                    for wl in range(2):
+                        hb = WN * c + 2 * sub + wl
+                        assert np.array_equal(aux[wl * 64:wl * 64 + 32], b1[32 * hb:32 * hb + 32])
+                        assert np.array_equal(aux[wl * 64 + 32:wl * 64 + 64], b1[4 * C + 32 * hb:4 * C + 32 * hb + 32])
+        for wn in range(WN):
+            hb = WN * c + wn
             assert np.array_equal(val[wn], w1[32 * hb:32 * hb + 32])
             assert np.array_equal(gate[wn], w1[4 * C + 32 * hb:4 * C + 32 * hb + 32])
-        got = np.zeros((C, 64), np.float16)
-        for i in range(2):                                   # XF_TILE(2, 5, 10, GB + (wm * 4 + 2 i) * 1024, 5 * wn, acc)
-            pieces, _ = _tile(blk.tail_stream, t0 + 4 + i)
-            for ksl in range(2):
-                for j in range(10):
-                    frag = pieces[ksl * 10 + j]
+        got = np.zeros((C, 32 * WN), np.float16)
+        for i in range(k["F2T"]):                            # XF_RUN_BODY(F2T, GNKS, 5, C / 32, GB + (wm * GKST + GNKS i + ks), 5 wn)
+            pieces, _ = _tile(blk.tail_stream, t0 + k["NSUB"] * k["F1T"] + i)
+            for ksl in range(k["GNKS"]):
+                for j in range(C // 32):
+                    frag = pieces[ksl * (C // 32) + j]
                     for lane in range(64):
                         lq, hi = lane & 31, lane >> 5
-                        got[32 * j + lq, 16 * (2 * i + ksl) + 8 * hi:][:8] = frag[lane]
-        assert np.array_equal(got, w2[:, 64 * c:64 * c + 64])
+                        got[32 * j + lq, 16 * (k["GNKS"] * i + ksl) + 8 * hi:][:8] = frag[lane]
+        assert np.array_equal(got, w2[:, 32 * WN * c:32 * WN * c + 32 * WN])
     prm = blk.tail_prm.numpy()
     for row, exp in enumerate((w["out1.b"].numpy(), fb("q2.w", "norm2"), w["out2.b"].numpy(), w["ff2.b"].numpy(),
                                w["proj_out.b"].numpy())):
@@ -115,9 +135,9 @@ def _xoff(rowblk, kst, col, lq):  # xformer.hip: xoff()
 def test_operand_image_offsets_are_consistent():
     """An accumulator quad written at xoff() is read back by the A-side fragment read `(rowblk * kst + kstep) * 1024 +
     lane * 16` as columns 16 kstep + 8 hi + e of row lq."""
-    for kst in (20, 4):
+    for kst, nrb in ((20, 4), (4, 4), (40, 2), (8, 2)):   # X / chunk image at C = 320, at C = 640
         seen = set()
-        for rb in range(4):
+        for rb in range(nrb):
             for col in range(0, 16 * kst, 4):
                 for lq in range(32):
                     off = _xoff(rb, kst, col, lq)
@@ -125,11 +145,12 @@ def test_operand_image_offsets_are_consistent():
                     assert off == (rb * kst + kstep) * 1024 + (hi * 32 + lq) * 16 + e0 * 2
                     assert off % 8 == 0 and off not in seen
                     seen.add(off)
-        assert len(seen) * 8 == 4 * 32 * 16 * kst * 2  # the image is covered exactly once
+        assert len(seen) * 8 == nrb * 32 * 16 * kst * 2  # the image is covered exactly once
 
 
-def test_context_fragments_are_what_the_kernel_reads():
-    B, heads, Lk = 2, 5, 77
+@pytest.mark.parametrize("C", [320, 640])
+def test_context_fragments_are_what_the_kernel_reads(C):
+    B, heads, Lk = 2, C // 64, 77
     g = torch.Generator().manual_seed(3)
     k = torch.randn(B, Lk, C, generator=g).half()
     vt = torch.randn(B, C, 80, generator=g).half()
@@ -153,9 +174,9 @@ def test_context_fragments_are_what_the_kernel_reads():
                             assert vfn[b, h, t, s, lane, p] == exp
 
 
-def _small_unet():
+def _small_unet(ch=320):
     from diffbir_amd.model.unet import ControlledUnetModel
-    cfg = configs._unet(320, 64, mult=(1,), attn=(1,), nrb=1)
+    cfg = configs._unet(ch, 64, mult=(1,), attn=(1,), nrb=1)
     net = ControlledUnetModel(**cfg)
     net.load_state_dict(synth_state_dict(net._spec, seed=5), strict=True)
     net._dtype, net._packed = torch.float32, False
@@ -163,14 +184,15 @@ def _small_unet():
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("pair", [None, (1, 1)])
-def test_fused_block_wiring_equals_per_launch_path(monkeypatch, pair):
+@pytest.mark.parametrize("pair,ch", [(None, 320), ((1, 1), 320), (None, 640)])
+def test_fused_block_wiring_equals_per_launch_path(monkeypatch, pair, ch):
     """groupnorm_affine -> xf_head -> attention -> xf_tail (test double, f32) == the 16-launch path, with and without
     the shared CFG prefix (pair_bs source-row mapping, full-batch text context)."""
     emu_ops.install(monkeypatch)
     from diffbir_amd.model import unet as unet_mod
-    assert unet_mod.FUSED_XF
-    net = _small_unet()
+    assert unet_mod.FUSED_XF and ch in unet_mod.FUSED_XF_WIDTHS
+    monkeypatch.setattr(xformer, "MIN_PANELS_640", 1)     # (the C = 640 kernels are dispatched from ~160 panels on)
+    net = _small_unet(ch)
     g = torch.Generator().manual_seed(1)
     x1 = torch.randn(1, 4, 16, 8, generator=g)           # latent 16 x 8 -> L = 128 rows per sample
     x = torch.cat([x1, x1]) if pair else torch.randn(2, 4, 16, 8, generator=g)
