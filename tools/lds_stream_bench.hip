@@ -80,6 +80,94 @@ __global__ __launch_bounds__(512) void stream_kernel(const char* w, int ntiles, 
   if (s == 123.456f) sink[0] = s;
 }
 
+// Producer / consumer split: waves 0-7 only read fragments and issue MFMAs, NLOAD extra waves only issue the direct-to-LDS
+// copies of the weight tiles (and wait for them): does the copy then run UNDER the MFMAs instead of in front of them?
+// (one workgroup barrier per tile as above; loader l copies pieces l, l + NLOAD, ... of a tile, loader 0 also the side data)
+template <int MFMAS, int NLOAD>
+__global__ __launch_bounds__(64 * (8 + NLOAD)) void stream_spec_kernel(const char* w, int ntiles, int iters, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, ntiles * TILE, 0x00020000);
+  const int lane16 = lane * 16;
+  constexpr int PPL = 20 / NLOAD;  // full pieces per loader and tile
+  f32x16 acc[5];
+  for (int j = 0; j < 5; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  if (wave >= 8) {
+    const int l = wave - 8;
+    int s_t = 0, s_slot = 0;
+#define LSTAGE()                                                                                                     \
+  do {                                                                                                               \
+    char* dst = smem + s_slot * TILE;                                                                                \
+    const int so = s_t * TILE;                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < PPL; ++q)                                                                  \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(dst + (l + q * NLOAD) * 1024), 16, lane16,            \
+                                                 so + (l + q * NLOAD) * 1024, 0, 0);                                 \
+    if (l == 0) {                                                                                                    \
+      if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(dst + 20480), 16, lane16, so + 20480, 0, 0); \
+    }                                                                                                                \
+    s_slot = s_slot + 1 == NSLOT ? 0 : s_slot + 1;                                                                   \
+    s_t = s_t + 1 == ntiles ? 0 : s_t + 1;                                                                           \
+  } while (0)
+    LSTAGE();
+    LSTAGE();
+    for (int it = 0; it < iters; ++it) {
+      // tile `it` landed: at most the loads of tile it + 1 may stay in flight
+      if (it + 1 < iters + 1) {
+        if (l == 0) wait_vm<PPL + 1>(); else wait_vm<PPL>();
+      }
+      asm volatile("s_barrier" ::: "memory");
+      if (it + 2 < iters + 2) LSTAGE();  // into the slot the consumers finished before this barrier
+    }
+    wait_vm<0>();
+#undef LSTAGE
+    return;
+  }
+  int c_slot = 0;
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const char* base = smem + c_slot * TILE;
+    c_slot = c_slot + 1 == NSLOT ? 0 : c_slot + 1;
+    if (MFMAS) {
+      f16x8 xf = *reinterpret_cast<const f16x8*>(base + lane16);
+      f16x8 wf[5];
+      for (int j = 0; j < 5; ++j) wf[j] = *reinterpret_cast<const f16x8*>(base + (1 + j + (wave & 3)) * 1024 + lane16);
+#pragma unroll
+      for (int ks = 0; ks < MFMAS / 5; ++ks)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf, acc[j], 0, 0, 0);
+    }
+  }
+  float sres = 0.f;
+  for (int j = 0; j < 5; ++j)
+    for (int r = 0; r < 16; ++r) sres += acc[j][r];
+  if (sres == 123.456f) sink[0] = sres;
+}
+
+template <int MFMAS, int NLOAD>
+static void run_spec(const char* w, int ntiles, int iters, float* sink, const char* what) {
+  auto kern = &stream_spec_kernel<MFMAS, NLOAD>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * TILE);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(64 * (8 + NLOAD)), NSLOT * TILE, 0, w, ntiles, iters, sink);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  const double bytes = 256.0 * iters * TILE;
+  printf("%-34s stream %7.1f MB  mfma/tile/wave %2d  %8.1f us  %7.1f GB/s per CU  %6.2f TB/s aggregate  (%.2f us per tile)\n", what,
+         ntiles * (double)TILE / 1e6, MFMAS, best * 1e3, bytes / 256 / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e12,
+         best * 1e3 / iters);
+}
+
 template <int MFMAS>
 static void run(const char* w, int ntiles, int iters, int skew, float* sink, const char* what) {
   auto kern = &stream_kernel<MFMAS>;
@@ -116,6 +204,15 @@ int main() {
     run<0>(w, ntiles, iters, 1, sink, "copy only, skewed start");
     run<10>(w, ntiles, iters, 0, sink, "copy + MFMAs, same tile");
     run<10>(w, ntiles, iters, 1, sink, "copy + MFMAs, skewed start");
+    if (ntiles <= 640) {
+      run<5>(w, ntiles, iters, 0, sink, "copy + 5 MFMAs, same tile");
+      run_spec<10, 2>(w, ntiles, iters, sink, "8 MFMA waves + 2 loader waves");
+      run_spec<10, 4>(w, ntiles, iters, sink, "8 MFMA waves + 4 loader waves");
+      run_spec<5, 2>(w, ntiles, iters, sink, "8 MFMA waves (5) + 2 loaders");
+      run_spec<5, 4>(w, ntiles, iters, sink, "8 MFMA waves (5) + 4 loaders");
+      run_spec<0, 2>(w, ntiles, iters, sink, "no MFMAs, 2 loader waves");
+      run_spec<0, 4>(w, ntiles, iters, sink, "no MFMAs, 4 loader waves");
+    }
   }
   return 0;
 }

@@ -64,9 +64,9 @@ for C in widths:
         out = torch.empty_like(x)
         for _ in range(2):
             plain(attn, h, x, k, vt, L)       # (first use tunes / looks up the tiles)
-        t_tail = timeit(lambda: ops.xf_tail(attn, h, x, blk, kf, vf, Lk, 0.125, L, out=out))
-        t_head = timeit(lambda: ops.xf_head(x, ab, blk, L))
         t_plain = timeit(lambda: plain(attn, h, x, k, vt, L))
         fl_t, fl_h = 2.0 * M * C * 16 * C, 2.0 * M * C * 4 * C
+        t_tail = timeit(lambda: ops.xf_tail(attn, h, x, blk, kf, vf, Lk, 0.125, L, out=out))
+        t_head = timeit(lambda: ops.xf_head(x, ab, blk, L))
         print(f"C{C} B{B} (M {M}): xf_tail {t_tail:7.1f} us ({fl_t / t_tail / 1e6:6.0f} TF/s)   per-launch tail {t_plain:7.1f} us   "
               f"xf_head {t_head:6.1f} us ({fl_h / t_head / 1e6:5.0f} TF/s)", flush=True)
