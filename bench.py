@@ -192,7 +192,7 @@ def measure_roofline(cldm, device, batch, pmc=False):
         a[2] += 1
         a[3] += nbytes
     g = tot.get("gemm", [0.0, 1.0, 1, 0.0])
-    out = dict(bound="mfma", kernel="implicit-GEMM conv/linear family (gemm_halo_kernel / gemm_glds_kernel / gemm_kernel)",
+    out = dict(bound="mfma", kernel="implicit-GEMM conv / linear family (gemm_halo / gemm_glds / gemm_pers / gemm kernels, split-K reduce, fused transformer kernels xf_head / xf_tail)",
                achieved=g[0] / g[1] / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=g[0] / g[1] / MFMA_PEAK,
                traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1], eval_batch=2 * batch,
                avg_launch_us=g[1] / g[2] * 1e6, flops_per_launch=g[0] / g[2],
