@@ -87,16 +87,26 @@ __device__ __forceinline__ void wait_vmcnt() {
 // the first fragment reads of tile kt + 1 and the refill of tile kt's slot: the LDS latency and the barrier skew of a tile
 // boundary hide under MI x NJ armed MFMAs instead of standing between two tiles, and the ring runs one tile deeper (the
 // schedule measured on the fused transformer kernels, xformer.hip: 1300 -> 1100 cycles per 10-MFMA tile).
-template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE, int DEPH, int BKT, int XPF = 0>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2Params p) {
+// LDW > 0 (producer / consumer split, tiles 90 - 92): the block has LDW extra LOADER waves that issue every direct-to-LDS
+// copy (and do nothing else) while the WM x WN matrix waves only read fragments and issue MFMAs.  A wave that issues the
+// copies stalls in VMEM issue while the copy engine drains (~34 B/clk per CU) and, issuing in order, cannot start its MFMAs
+// behind them; with the stall on separate waves the copy of K tile kt + 2 runs UNDER the MFMAs of tile kt instead of in
+// front of them (tools/lds_stream_bench.hip: 0.49 -> 0.37 us per 20 KB tile with 10 MFMAs per wave = the pure MFMA time).
+// One workgroup barrier per K tile: loaders wait for tile kt (counted vmcnt) in front of it and refill the slot of tile
+// kt - 1 behind it; matrix waves finish their fragment reads of tile kt - 1 (lgkmcnt(0)) in front of it.  Loaders leave
+// after the K loop (an ended wave no longer takes part in barriers), the matrix waves run the epilogue.
+template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int MINW, int PIPE, int DEPH, int BKT, int XPF = 0,
+          int LDW = 0>
+__global__ __launch_bounds__(64 * (WM * WN + LDW), MINW) void gemm_glds_kernel(const G2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses gfx950-only builtins (buffer descriptors, LDS-DMA, MFMA)
-  constexpr int NT = 64 * WM * WN;
+  constexpr int NT = 64 * WM * WN;             // matrix-wave threads (the epilogue's thread count)
+  constexpr int NTS = LDW ? 64 * LDW : NT;     // threads that stage operand tiles
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int BK = BKT;                      // shadows the file-scope default inside the kernel
   constexpr int ROWB = BK * 2, CPR = BK / 8;   // bytes / 16-byte chunks per LDS tile row
   constexpr int KS = BK / 16;                  // MFMA k-steps per tile
-  constexpr int RPP = NT / CPR;                // tile rows covered by one glds pass of the whole block
-  constexpr int PASS_BYTES = NT * 16;
+  constexpr int RPP = NTS / CPR;               // tile rows covered by one glds pass of the staging threads
+  constexpr int PASS_BYTES = NTS * 16;
   constexpr int RA = BM / RPP, RB = (BN + RPP - 1) / RPP;  // glds per thread per stage (activation / weight tile)
   constexpr int LOADS = RA + RB;
   // BN = 160 (NJ = 5) is not a multiple of the pass height: the weight region is rounded up to whole passes and the
@@ -113,6 +123,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   const int wm = wave / WN, wn = wave % WN;
   const int lq = lane & 31, hi = lane >> 5;
   const int bz = blockIdx.y;
+  const bool loader = LDW > 0 && wave >= WM * WN;
+  const int stid = LDW ? tid - NT : tid;       // index among the staging threads (negative: a matrix wave of an LDW block)
+  const int swave = LDW ? wave - WM * WN : wave;
 
   // ---- XCD-aware tile mapping (bijective) ----
   int tm, tn, ksp;
@@ -134,9 +147,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   // swizzle key of a tile row: 128-byte rows (BK 64): (row >> 1) & 7 — two rows fill a 256-byte bank line; 64-byte rows
   // (BK 32): (row >> 2) & 3 — four rows per bank line.  Either way the 16 lanes of a ds_read_b128 service group (rows
   // distinct mod 16, same logical chunk) land in 16 distinct 16-byte slots.
-  const int srow = tid / CPR;
+  const int srow = (stid < 0 ? 0 : stid) / CPR;
   const int skey = BK == 64 ? ((srow >> 1) & 7) : ((srow >> 2) & 3);
-  const int cch = ((tid % CPR) ^ skey) * 8;  // logical K offset (halfs) of the chunk this thread fetches
+  const int cch = (((stid < 0 ? 0 : stid) % CPR) ^ skey) * 8;  // logical K offset (halfs) of the chunk this thread fetches
   const bool conv = d.mode == DBIR_MODE_CONV3X3;
 
   // Operands are fetched with `buffer_load_dwordx4 ... lds` through two block-local buffer descriptors (SRD): the
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
 // issue the direct-to-LDS loads of K tile s_kt into ring slot s_slot, then advance the cursor
 #define STAGE()                                                                                     \
   do {                                                                                              \
-    char* ab_ = smem + s_slot * BUF_BYTES + wave * 1024;                                            \
+    char* ab_ = smem + s_slot * BUF_BYTES + swave * 1024;                                           \
     char* bb_ = ab_ + A_BYTES;                                                                      \
     const int ky_ = (s_tap * 11) >> 5, kx_ = s_tap - 3 * ky_;                                       \
     const int koff_ = s_cc * (BK * 2);                          /* bytes, scalar operand */         \
@@ -287,9 +300,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (p.nkc * p.ntaps - kt0 < p.kt_per) ? p.nkc * p.ntaps - kt0 : p.kt_per;
+  if (!LDW || loader) {
 #pragma unroll
-  for (int s = 0; s < (DEPH ? 1 : STAGES - 1); ++s)
-    if (s < nk) STAGE();
+    for (int s = 0; s < (DEPH ? 1 : STAGES - 1); ++s)
+      if (s < nk) STAGE();
+  }
 
   // fragment read offsets (bytes) inside a stage: row * 128 + ((2*ks + hi) ^ key(row)) * 16
   const int a_frag = (wm * 32 * MI + lq) * ROWB;
@@ -298,7 +313,45 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_glds_kernel(const G2P
   constexpr int FSTR = 32 * ROWB;  // bytes between consecutive 32-row MFMA blocks
 
   int c_slot = 0;
-  if constexpr (DEPH) {
+  if constexpr (LDW > 0) {
+    static_assert(!DEPH && !XPF && PIPE == 1 && STAGES >= 3, "producer / consumer tiles: lockstep, pipelined reads, >= 3 slots");
+    if (loader) {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + STAGES - 2 < nk)
+          wait_vmcnt<(STAGES - 2) * LOADS>();   // tile kt landed; up to STAGES - 2 later tiles stay in flight
+        else
+          wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + STAGES - 1 < nk) STAGE();      // into the slot of tile kt - 1 (its readers passed lgkmcnt(0) + this barrier)
+      }
+      return;
+    }
+    typename T::vec8 xf[2][MI], wf[2][NJ];
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const char* base = smem + c_slot * BUF_BYTES;
+      c_slot = (c_slot + 1 == STAGES) ? 0 : c_slot + 1;
+#define LOAD_FRAGS_P(KS_, SET)                                                                                \
+  do {                                                                                                        \
+    const int co_ = ((2 * (KS_) + hi) ^ sw) * 16;                                                             \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) wf[SET][j] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(base + b_frag + j * FSTR + co_);                           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) xf[SET][i] =                                               \
+        *reinterpret_cast<const typename T::vec8*>(base + a_frag + i * FSTR + co_);                           \
+  } while (0)
+      LOAD_FRAGS_P(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks < KS - 1) LOAD_FRAGS_P(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[ks & 1][j], xf[ks & 1][i], acc[i][j]);  // D[n][m]
+      }
+#undef LOAD_FRAGS_P
+    }
+  } else if constexpr (DEPH) {
     static_assert(STAGES == 3 && PIPE == 1 && (WM * WN) % 2 == 0, "DEPH needs a 3-slot ring and two wave groups");
     const int grp = wave >= (WM * WN) / 2 ? 1 : 0;
     wait_vmcnt<0>();
@@ -562,18 +615,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
 }
 
 template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0, int BKT = 64, int WPS = 0,
-          int XPF = 0>
+          int XPF = 0, int LDW = 0>
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-  constexpr int RPP_ = 64 * WM * WN / (BKT / 8), BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
+  constexpr int RPP_ = 64 * (LDW ? LDW : WM * WN) / (BKT / 8), BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
   constexpr int ring = STAGES * (BM + BNR) * BKT * 2, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
   constexpr int lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   constexpr int blocks_per_cu = (160 * 1024) / lds;
-  constexpr int waves = WM * WN * (blocks_per_cu > 2 ? 2 : blocks_per_cu);
+  constexpr int waves = (WM * WN + LDW) * (blocks_per_cu > 2 ? 2 : blocks_per_cu);
   // WPS > 0: explicit waves per SIMD (register budget 512 / WPS) for variants meant to run several blocks per CU
-  constexpr int MINW = WPS > 0 ? WPS : (waves >= 8 ? 2 : 1);
-  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE, DEPH, BKT, XPF>;
+  constexpr int MINW = WPS > 0 ? WPS : (waves > 8 ? 3 : (waves >= 8 ? 2 : 1));
+  auto kern = &gemm_glds_kernel<T, WM, WN, MI, NJ, STAGES, MINW, PIPE, DEPH, BKT, XPF, LDW>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -611,7 +664,11 @@ int launch2(G2Params& p, hipStream_t s) {
   }
   const unsigned nz = p.d.batch > 0 ? p.d.batch : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles * p.splitk), nz);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
+  if (LDW && p.splitk > 1) {
+    dbir_set_error("dbir_gemm: the producer / consumer tiles (90 - 92) do not do split-K");
+    return DBIR_ERR_ARG;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + LDW)), lds, s, p);
   DBIR_CHECK_LAUNCH("dbir_gemm(glds)");
   if (p.splitk > 1) {
     const long long work = (long long)p.d.M * (p.d.N >> 3);
@@ -664,6 +721,11 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
     case 86: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 32, 4, 1>(p, s);   // 256x128, K depth 32, 3 slots, 2 blocks / CU
     case 87: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 32, 3, 1>(p, s);   // 128x128, K depth 32, 3 slots, 3 blocks / CU
     case 88: return launch2<T, 2, 4, 4, 2, 4, 1, 0, 32, 0, 1>(p, s);   // 256x256, K depth 32, 4 slots
+    // 90 - 92: producer / consumer split (LDW = 4 loader waves + the matrix waves), 3-slot ring (a 256x160 variant with 8
+    // matrix waves needs > 168 VGPRs at three waves per SIMD and spilled: measured slower everywhere, not kept)
+    case 90: return launch2<T, 4, 1, 1, 5, 3, 1, 0, 64, 0, 0, 4>(p, s);   // 128x160, 4 matrix waves (32x160 each)
+    case 91: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 64, 0, 0, 4>(p, s);   // 128x128, 4 matrix waves (64x64 each)
+    case 92: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 64, 0, 0, 4>(p, s);   // 256x128, 8 matrix waves (64x64 each)
   }
   dbir_set_error("dbir_gemm: bad glds tile %d", tile);
   return DBIR_ERR_ARG;
@@ -757,7 +819,7 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
       tile = 5;
   }
   if (dd.act == DBIR_ACT_GEGLU && (tile == 14 || tile == 15 || tile == 16 || tile == 34 || tile == 35 || tile == 37 || tile == 38 ||
-                                   tile == 84 || tile == 85)) {
+                                   tile == 84 || tile == 85 || tile == 90)) {
     dbir_set_error("dbir_gemm: GEGLU needs a tile whose waves hold value/gate column pairs (tiles 5-13)");
     return DBIR_ERR_ARG;
   }
