@@ -31,7 +31,8 @@ class ControlLDM:
         # engine option: run the ControlNet on a second HIP stream while the UNet encoder (which does not depend on it,
         # controlnet.py:30-38) runs on the current one; the streams join before the middle-block control is added.
         # The two networks have the same shapes, and the 16x16 / 8x8 latent levels alone cannot fill 256 CUs.
-        self.overlap_streams = True
+        # ControlNet on a side stream next to the UNet encoder (DBIR_OVERLAP_STREAMS=0: one stream, A/B)
+        self.overlap_streams = os.environ.get("DBIR_OVERLAP_STREAMS", "1") != "0"
         self._side_stream = {}
         # engine option: capture one network evaluation (ControlNet + UNet, ~700 kernel launches from Python through
         # ctypes, ~20 ms of host time) into a HIP graph per (shape, text context, control scales) and replay it every
