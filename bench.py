@@ -374,8 +374,11 @@ def main():
         pipe, cldm, swin = build_engine(device, dtype, ctx)
         if world > 1:
             extra["weights"] = "generated on rank 0, shipped by parallel.broadcast_state_dict (RCCL, 256 MB buckets)"
-            extra["rccl"] = dict(ranks=dist.get_world_size(), backend=dist.get_backend(),
-                                 version=".".join(str(v) for v in torch.cuda.nccl.version()))
+            try:   # informational only: never let it break a multi-GPU run
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001
+                ver = f"unknown ({type(e).__name__})"
+            extra["rccl"] = dict(ranks=dist.get_world_size(), backend=dist.get_backend(), version=ver)
         rs = np.random.RandomState(100 + (0 if cfg["tiled"] else rank))
         lq = rs.randint(0, 256, (args.batch, cfg["size"], cfg["size"], 3)).astype(np.uint8)
         lq_dev = torch.as_tensor(lq).to(device)          # inputs resident in HBM before the timed region

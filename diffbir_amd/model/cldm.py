@@ -19,6 +19,11 @@ from .vae import AutoencoderKL
 T = torch.Tensor
 
 
+# skip-connection injections (zero conv + skip add, 12 GEMMs) issued on the ControlNet's stream beside the UNet's middle
+# block instead of inside the decoder (DBIR_INJECT_SIDE=0: A/B)
+INJECT_ON_SIDE_STREAM = os.environ.get("DBIR_INJECT_SIDE", "1") != "0"
+
+
 class ControlLDM:
     def __init__(self, unet_cfg, vae_cfg, clip_cfg, controlnet_cfg, latent_scale_factor):
         self.unet = ControlledUnetModel(**unet_cfg)
@@ -188,7 +193,8 @@ class ControlLDM:
         for c in feats:                             # allocated on `side`, consumed (and later freed) on `main`
             c.record_stream(main)
         return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, control_ready=done, pair=pair, t_host=th,
-                         control_feats=(feats, cn.zero, self.control_scales))
+                         control_feats=(feats, cn.zero, self.control_scales),
+                         control_stream=side if INJECT_ON_SIDE_STREAM else None)
 
     def _forward_eager_unfused(self, x_noisy: T, t: T, c_txt: T, c_img: T, pair) -> T:
         if not (self.overlap_streams and x_noisy.is_cuda):

@@ -340,7 +340,7 @@ class ControlledUnetModel(_DiffusionNet):
 
     def forward(self, x: T, timesteps: T, context: T, control: Optional[List[T]] = None,
                 only_mid_control: bool = False, control_ready=None, pair: Pair = None, control_feats=None,
-                t_host: Optional[float] = None, **_) -> T:
+                t_host: Optional[float] = None, control_stream=None, **_) -> T:
         """x: f32 NCHW [B,4,h,w]; control: list of 13 NHWC 16-bit tensors (already scaled) or None -> f32 NCHW.
         control_ready: optional torch.cuda.Event recorded by the stream that produces `control` (ControlLDM runs the
         ControlNet concurrently with this encoder); waited for right before the first control tensor is read.
@@ -349,7 +349,11 @@ class ControlledUnetModel(_DiffusionNet):
         control_feats=(feats, zero_convs, scales): instead of `control`, the ControlNet's 13 pre-zero-conv feature maps
         (`ControlNet.features`), its packed zero convs and the control scales: `skip + zero_conv(f) * scale` is then ONE
         GEMM per skip connection, written straight into the concat buffer (same arithmetic: the control tensor is
-        rounded to 16 bit before the add in both forms)."""
+        rounded to 16 bit before the add in both forms).
+        control_stream: the stream that produced the features (ControlLDM's side stream).  The 12 skip injections depend
+        only on the two encoders, not on the decoder, so they are issued on THAT stream, in decoder order, as soon as both
+        encoders are done, and run BESIDE the decoder blocks instead of between them (decoder block i waits for the event of
+        its own injection only)."""
         self._ensure_packed()
         ctx_kv = self.context_kv(context)
         emb_all = self._time_emb(timesteps, t_host)
@@ -382,9 +386,40 @@ class ControlledUnetModel(_DiffusionNet):
         def cat_buf(blk, hh, ww):
             return torch.empty((B, hh, ww, blk["cin"]), dtype=self._dtype, device=h.device)
 
+        # the decoder's concat buffers: [left = previous output | right = skip + control]
+        bufs, hh, ww = [], h.shape[1], h.shape[2]
+        for res, att, up, b in self.dec:
+            bufs.append(cat_buf(b, hh, ww))
+            if up is not None:
+                hh, ww = 2 * hh, 2 * ww
+        pre = None   # skip injections issued ahead on the control stream: per decoder block (column sums | None, event)
+        if control_feats is not None and control_stream is not None and not only_mid_control and h.is_cuda:
+            main = torch.cuda.current_stream()
+            enc_done = torch.cuda.Event()
+            enc_done.record(main)                   # hs (this encoder's skips) are complete
+            pre = []
+            with torch.cuda.stream(control_stream):
+                control_stream.wait_event(enc_done)
+                for i, (res, att, up, b) in enumerate(self.dec):
+                    f, z, sc = cf[-2 - i]           # cf[-1] is the middle block's feature, then the skips last to first
+                    right = bufs[i][..., b["cin"] - b["skip"]:]
+                    st = None
+                    if GN_EPI_STATS:
+                        st = ops.linear(f, z, out_scale=sc, residual=hs[-1 - i], out=right, stats=True)[1]
+                    else:
+                        ops.linear(f, z, out_scale=sc, residual=hs[-1 - i], out=right)
+                    ev = torch.cuda.Event()
+                    ev.record(control_stream)       # decoder block i waits for ITS injection only: the rest run beside it
+                    pre.append((st, ev))
+            for st, _ev in pre:                     # allocated on the control stream, consumed (and freed) on this one
+                if st is not None:
+                    st.buf.record_stream(main)
+            mid_feat = cf.pop()
+            del cf[:]
+            cf.append(mid_feat)
         # middle output (+ control) goes straight into the left part of the first concat buffer
         b0 = self.plan.output[0]
-        buf = cat_buf(b0, h.shape[1], h.shape[2])
+        buf = bufs[0]
         left = buf[..., : b0["cin"] - b0["skip"]]
         done, lst = add_control(h, left)     # lst / rst: column sums of the buffer's left / right part (GroupNorm statistics)
         if not done:
@@ -392,15 +427,16 @@ class ControlledUnetModel(_DiffusionNet):
         for i, (res, att, up, b) in enumerate(self.dec):
             skip = hs.pop()
             right = buf[..., b["cin"] - b["skip"]:]
-            done, rst = (False, None) if only_mid_control else add_control(skip, right)
+            if pre is not None:
+                torch.cuda.current_stream().wait_event(pre[i][1])
+                done, rst = True, pre[i][0]
+            else:
+                done, rst = (False, None) if only_mid_control else add_control(skip, right)
             if not done:
                 right.copy_(skip)
             last = i == len(self.dec) - 1
             nxt = None if last else self.plan.output[i + 1]
-            hh, ww = buf.shape[1], buf.shape[2]
-            if up is not None:
-                hh, ww = 2 * hh, 2 * ww
-            nbuf = None if last else cat_buf(nxt, hh, ww)
+            nbuf = None if last else bufs[i + 1]
             target = None if last else nbuf[..., : nxt["cin"] - nxt["skip"]]
             xst = (lst, rst) if (lst is not None and rst is not None) else None
             if up is None:
