@@ -323,7 +323,7 @@ static int dbir_gemm_impl(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 92 && tile != 13 && !(tile >= 74 && tile <= 79) && tile != 89, "dbir_gemm: bad tile %d", tile);
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 92 && tile != 13 && !(tile >= 74 && tile <= 89), "dbir_gemm: bad tile %d", tile);
   if (tile >= 70 && tile < 80) {
     DBIR_CHECK_ARG(dbir_gemm_pers_eligible(d, tile),
                    "dbir_gemm: tile %d (persistent linear kernel) needs a dense linear with K %% 32 == 0, M a multiple of "

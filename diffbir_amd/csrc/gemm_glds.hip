@@ -711,16 +711,9 @@ int dispatch2(G2Params& p, int tile, hipStream_t s) {
     // epilogue (HBM-bound, GELU-heavy for GEGLU) overlaps another block's K loop without any in-kernel scheduling
     case 44: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 32, 4>(p, s);  // 256x128, 8 waves (64x64 each), 3-slot ring, 72 KB
     case 45: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 32, 3>(p, s);  // 128x128, 4 waves, 3-slot ring, 48 KB: 3 blocks / CU
-    // 80 - 88: lockstep tiles with cross-tile fragment prefetch (XPF = 1): 25 / 30 / 32 / 34 / 35 / 44 / 45 / 41 / 12-with-3-slots
-    case 80: return launch2<T, 2, 2, 2, 2, 2, 1, 0, 64, 0, 1>(p, s);   // 128x128, 4 waves, 2 slots
-    case 81: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 64, 0, 1>(p, s);   // 128x128, 4 waves, 3 slots
-    case 82: return launch2<T, 2, 4, 4, 2, 2, 1, 0, 64, 0, 1>(p, s);   // 256x256, 2 slots
-    case 83: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 64, 0, 1>(p, s);   // 256x128, 8 waves, 3 slots
-    case 84: return launch2<T, 8, 1, 1, 5, 2, 1, 0, 64, 0, 1>(p, s);   // 256x160, 8 waves, 2 slots
-    case 85: return launch2<T, 4, 1, 1, 5, 3, 1, 0, 64, 0, 1>(p, s);   // 128x160, 4 waves, 3 slots
-    case 86: return launch2<T, 4, 2, 2, 2, 3, 1, 0, 32, 4, 1>(p, s);   // 256x128, K depth 32, 3 slots, 2 blocks / CU
-    case 87: return launch2<T, 2, 2, 2, 2, 3, 1, 0, 32, 3, 1>(p, s);   // 128x128, K depth 32, 3 slots, 3 blocks / CU
-    case 88: return launch2<T, 2, 4, 4, 2, 4, 1, 0, 32, 0, 1>(p, s);   // 256x256, K depth 32, 4 slots
+    // (80 - 88, round 3: the lockstep tiles with cross-tile fragment prefetch, XPF = 1 — 0.98 - 1.02x the incumbents on every
+    // shape, profiles/r3_autotune_xprefetch_tiles_b8.log — are no longer instantiated; the schedule stays in the kernel
+    // template as the reference for the fused transformer kernels' tile loop, which uses it)
     // 90 - 92: producer / consumer split (LDW = 4 loader waves + the matrix waves), 3-slot ring (a 256x160 variant with 8
     // matrix waves needs > 168 VGPRs at three waves per SIMD and spilled: measured slower everywhere, not kept)
     case 90: return launch2<T, 4, 1, 1, 5, 3, 1, 0, 64, 0, 0, 4>(p, s);   // 128x160, 4 matrix waves (32x160 each)
@@ -819,7 +812,7 @@ int dbir_gemm_glds(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream
       tile = 5;
   }
   if (dd.act == DBIR_ACT_GEGLU && (tile == 14 || tile == 15 || tile == 16 || tile == 34 || tile == 35 || tile == 37 || tile == 38 ||
-                                   tile == 84 || tile == 85 || tile == 90)) {
+                                   tile == 90)) {
     dbir_set_error("dbir_gemm: GEGLU needs a tile whose waves hold value/gate column pairs (tiles 5-13)");
     return DBIR_ERR_ARG;
   }

@@ -105,13 +105,10 @@ typedef struct dbir_gemm_desc {
                register epilogue: 256x160 / 128x160 (two workgroups per CU) / 256x128 / 128x128 (two per CU); dense
                linear with K % 32 == 0, M a multiple of the tile height, N % 8 == 0, no row vector / split-K /
                transposed or f32 store;
-               80 - 88: direct-to-LDS lockstep tiles with cross-tile fragment prefetch (the acquire of K tile kt + 1 sits
-               ahead of tile kt's last k-step): 128x128 (2 / 3 slots), 256x256, 256x128, 256x160, 128x160, then K depth 32:
-               256x128 (2 blocks / CU), 128x128 (3 blocks / CU), 256x256 (4 slots);
                90 - 92: producer / consumer split — four extra loader waves issue every direct-to-LDS copy, the matrix
                waves only read fragments and issue MFMAs (3-slot ring, one barrier per K tile, no split-K): 128x160 (4 matrix
                waves), 128x128 (4), 256x128 (8).
-               Ids 60 - 67 exist only in a DBIR_DIAG build (diagnostic ablations, meaningless outputs); 13, 74 - 79 and 89
+               Ids 60 - 67 exist only in a DBIR_DIAG build (diagnostic ablations, meaningless outputs); 13 and 74 - 89
                are invalid. */
   /* split-K (direct-to-LDS tiles >= 5 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
    * into f32 partial sums in `ws` (>= splitk * batch * M * N * 4 bytes, 16-byte aligned, caller-owned), then a second

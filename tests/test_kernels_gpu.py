@@ -187,12 +187,10 @@ def test_conv3x3_fused_epilogue(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ direct-to-LDS GEMM
-GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41, 44, 45,
-              80, 81, 82, 83, 84, 85, 86, 87, 88, 90, 91, 92]
+GLDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41, 44, 45, 90, 91, 92]
 # 20 + t: tile t with pipelined fragment reads; 36-38: de-phased two-group variants; 40/41: K depth 32 (256x256);
-# 80-88: lockstep tiles with cross-tile fragment prefetch (the acquire of K tile kt + 1 ahead of tile kt's last k-step)
 # 90-92: producer / consumer split (4 loader waves stage the operands, the matrix waves only read fragments + MFMA)
-NO_GEGLU_TILES = (14, 15, 16, 34, 35, 37, 38, 84, 85, 90)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
+NO_GEGLU_TILES = (14, 15, 16, 34, 35, 37, 38, 90)   # 160-wide tiles: a wave's 5 column blocks cannot hold value/gate pairs
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
