@@ -11,7 +11,6 @@ from typing import Dict, List, Set, Tuple
 
 import torch
 
-from .base import NativeModule
 from .clip import FrozenOpenCLIPEmbedder
 from .unet import ControlledUnetModel, ControlNet
 from .vae import AutoencoderKL

@@ -15,7 +15,7 @@ module tree would hold:
   "w" dense weight (conv / linear), "b" bias, "g" norm gain, "e" embedding/table, "buf" non-learned buffer.
 """
 from collections import OrderedDict
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List
 
 Spec = "OrderedDict[str, Tuple[Tuple[int, ...], str]]"
 

@@ -8,7 +8,7 @@ attention (every query row sees all keys), but never an [L, L] matrix — L = 40
 at 4096x4096 (137 GB of scores if materialised) runs in 4 GB pieces.
 """
 import math
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 import torch
 

@@ -23,7 +23,7 @@ Nothing here touches the kernels' C ABI: collectives are issued from Python on t
 """
 import os
 from dataclasses import dataclass
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Callable, Dict, Optional, Tuple
 
 import numpy as np
 import torch

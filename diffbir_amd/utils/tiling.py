@@ -18,7 +18,6 @@ sequential loop: parity there is a tolerance (tests), not bit-exactness.
 """
 from typing import Callable, Dict, Optional, Tuple
 
-import numpy as np
 import torch
 
 from .. import ops

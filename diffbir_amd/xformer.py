@@ -27,7 +27,6 @@ column-scaled, the W beta rows are the accumulators' initial values (parameter r
   hidden units = two runs of 8 GEGLU-projection tiles in the C = 320 format (run s = hidden blocks 4c + 2s, 4c + 2s + 1),
   then 8 one-k-step tiles of ff.net.2 columns [128 c, 128 c + 128).)  `geometry(C)` has the numbers.
 """
-import ctypes
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
