@@ -406,58 +406,50 @@ __global__ void gn_finalize_affine(const u16* __restrict__ x, long long ldx, con
 
 namespace {
 // GroupNorm statistics from the column sums emitted by dbir_gemm epilogues (dbir_gemm_desc.stats): p[tile][2][N] with `rows`
-// rows per tile; the normalised tensor is [producer 1 columns | producer 2 columns].  One block per sample; a thread per
-// group sums (in double: a few hundred terms) over the sample's tiles and the group's channels.
-__global__ void gn_from_partials(const float* __restrict__ p1, int N1, const float* __restrict__ p2, int N2, int rows,
-                                 int HW, int groups, float eps, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float* __restrict__ mean_var,
-                                 float* __restrict__ scale_shift) {
-  __shared__ float stat[128];
-  __shared__ double red[2][256];
-  const int b = blockIdx.x, t = threadIdx.x;
+// rows per tile; the normalised tensor is [producer 1 columns | producer 2 columns].
+__global__ __launch_bounds__(256) void gn_from_partials(const float* __restrict__ p1, int N1, const float* __restrict__ p2,
+                                                        int N2, int rows, int HW, int groups, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ mean_var, float* __restrict__ scale_shift) {
+  // one wave per (sample, group), four groups per block: lane l sums the (tile, channel) cells l, l + 64, ... of its group in
+  // f64 (the per-tile sums are f32), then a butterfly over the wave — the first version walked a group with a few threads
+  // of ONE block per sample and took 7 us, as long as the statistics pass it replaces
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= groups) return;
   const int C = N1 + N2, cpg = C / groups, tiles = HW / rows;
-  // thread = (slice, group): `nsl` slices of the tile list per group, f64 partial sums, reduced through LDS
-  const int nsl = blockDim.x / groups, g0 = t % groups, sl = t / groups;
+  const int cells = tiles * cpg;
   double s = 0.0, q = 0.0;
-  if (sl < nsl) {
-    for (int ti = sl; ti < tiles; ti += nsl) {
-      const long long tile = (long long)b * tiles + ti;
-      for (int c = g0 * cpg; c < (g0 + 1) * cpg; ++c) {
-        if (c < N1) {
-          s += p1[tile * 2 * N1 + c];
-          q += p1[tile * 2 * N1 + N1 + c];
-        } else {
-          s += p2[tile * 2 * N2 + (c - N1)];
-          q += p2[tile * 2 * N2 + N2 + (c - N1)];
-        }
-      }
+  for (int idx = lane; idx < cells; idx += 64) {
+    const int ti = idx / cpg, c = g * cpg + (idx - ti * cpg);
+    const long long tile = (long long)b * tiles + ti;
+    if (c < N1) {
+      s += p1[tile * 2 * N1 + c];
+      q += p1[tile * 2 * N1 + N1 + c];
+    } else {
+      s += p2[tile * 2 * N2 + (c - N1)];
+      q += p2[tile * 2 * N2 + N2 + (c - N1)];
     }
   }
-  red[0][t] = s;
-  red[1][t] = q;
-  __syncthreads();
-  if (t < groups) {
-    for (int i = 1; i < nsl; ++i) {
-      s += red[0][i * groups + t];
-      q += red[1][i * groups + t];
-    }
-    const double n = (double)HW * cpg, mean = s / n;
-    double var = q / n - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    stat[t] = (float)mean;
-    stat[groups + t] = (float)var;
-    if (mean_var) {
-      mean_var[(long long)b * 2 * groups + t] = (float)mean;
-      mean_var[(long long)b * 2 * groups + groups + t] = (float)var;
-    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
   }
-  if (!scale_shift) return;
-  __syncthreads();
-  for (int c = t; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float a = rsqrtf(stat[groups + g] + eps) * gamma[c];
-    scale_shift[(long long)b * 2 * C + c] = a;
-    scale_shift[(long long)b * 2 * C + C + c] = beta[c] - stat[g] * a;
+  const double n = (double)HW * cpg, mean = s / n;
+  double var = q / n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  if (mean_var && lane == 0) {
+    mean_var[(long long)b * 2 * groups + g] = (float)mean;
+    mean_var[(long long)b * 2 * groups + groups + g] = (float)var;
+  }
+  if (scale_shift) {
+    const float rstd = rsqrtf((float)var + eps), mf = (float)mean;
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+      const float a = rstd * gamma[c];
+      scale_shift[(long long)b * 2 * C + c] = a;
+      scale_shift[(long long)b * 2 * C + C + c] = beta[c] - mf * a;
+    }
   }
 }
 }  // namespace
@@ -470,8 +462,8 @@ extern "C" int dbir_groupnorm_from_partials(const float* p1, int N1, const float
                  "dbir_groupnorm_from_partials: need HW %% rows == 0 (HW %d, rows %d), groups <= 64 dividing C", HW, rows);
   DBIR_CHECK_ARG(mean_var || scale_shift, "dbir_groupnorm_from_partials: no output requested");
   DBIR_CHECK_ARG(!scale_shift || (gamma && beta), "dbir_groupnorm_from_partials: scale_shift needs gamma / beta");
-  hipLaunchKernelGGL(gn_from_partials, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p1, N1, p2, N2, rows, HW,
-                     groups, eps, gamma, beta, mean_var, scale_shift);
+  hipLaunchKernelGGL(gn_from_partials, dim3((groups + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p1, N1,
+                     p2, N2, rows, HW, groups, eps, gamma, beta, mean_var, scale_shift);
   DBIR_CHECK_LAUNCH("dbir_groupnorm_from_partials");
   return DBIR_OK;
 }
