@@ -128,6 +128,17 @@ def test_weight_stream_is_what_the_kernel_reads(C):
                                                           fb("v1.w", "norm1")]))
 
 
+def test_dispatch_rule():
+    """Which blocks run on the fused kernels: C = 320 for any whole-panel sequence length; C = 640 only from ~160 panels of
+    64 rows on (one panel occupies a CU: fewer would leave most of the chip idle); text context <= 96 tokens."""
+    assert xformer.supported(320, 4096, 77) and xformer.supported(320, 128, 77, 128)
+    assert not xformer.supported(320, 192, 77) and not xformer.supported(320, 4096, 97) and not xformer.supported(1280, 256, 77)
+    assert xformer.supported(640, 1024, 77) and xformer.supported(640, 1024, 77, 16 * 1024)
+    assert xformer.supported(640, 1024, 77, xformer.MIN_PANELS_640 * 64)
+    assert not xformer.supported(640, 1024, 77, xformer.MIN_PANELS_640 * 64 - 64)
+    assert not xformer.supported(640, 96, 77) and not xformer.supported(640, 1024, 0)
+
+
 def _xoff(rowblk, kst, col, lq):  # xformer.hip: xoff()
     return ((rowblk * kst + (col >> 4)) * 2 + ((col >> 3) & 1)) * 512 + lq * 16 + ((col >> 2) & 1) * 8
 
