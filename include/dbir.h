@@ -35,6 +35,8 @@ extern "C" {
 #define DBIR_MODE_CONV3X3 1
 
 const char* dbir_last_error(void);
+/* 3 since round 3: dbir_gemm takes a non-const descriptor (stats / stats_rows fields at its end), dbir_xf_head / dbir_xf_tail /
+ * dbir_xf_geometry, dbir_groupnorm_affine, dbir_groupnorm_from_partials; tiles 80 - 89 retired, 90 - 92 added. */
 int dbir_abi_version(void);
 /* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 2 (default) = LDS-resident
  * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape. */

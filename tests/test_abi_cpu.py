@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert not missing, f"libdbir_hip.so does not export: {missing}"
     unbound = [n for n in declared if n not in native.SIGNATURES and n != "dbir_last_error"]
     assert not unbound, f"diffbir_amd.native.SIGNATURES lacks: {unbound}"
-    assert lib.dbir_abi_version() >= 2
+    assert lib.dbir_abi_version() >= 3
 
 
 def test_gemm_desc_layout_matches_header(tmp_path):
