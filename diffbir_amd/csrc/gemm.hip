@@ -278,6 +278,10 @@ int dbir_gemm_halo(const dbir_gemm_desc& d, int tile, hipStream_t s);
 bool dbir_gemm_pers_eligible(const dbir_gemm_desc& d, int tile);
 int dbir_gemm_pers(const dbir_gemm_desc& d, int tile, hipStream_t s);
 
+// fine-phase 256x320 kernel (gemm_8p.hip), tile 80
+bool dbir_gemm_8p_eligible(const dbir_gemm_desc& d);
+int dbir_gemm_8p(const dbir_gemm_desc& d, int Hv, int Wv, int tile, hipStream_t s);
+
 // rows per tile for which the launch that just ran emits GroupNorm column sums (dbir_gemm_desc.stats); set by the
 // direct-to-LDS / halo launchers, 0 otherwise
 thread_local int g_dbir_stats_rows = 0;
@@ -297,7 +301,8 @@ static int dbir_gemm_impl(const dbir_gemm_desc* dd, void* stream) {
   p.d = *dd;
   dbir_gemm_desc& d = p.d;
   // epilogue statistics: plain 16-bit row-major stores of the direct-to-LDS / halo kernels only
-  if (d.stats && (d.store_mode != 0 || d.out_f32 || d.act == DBIR_ACT_GEGLU || d.splitk > 1 || d.batch > 1 ||
+  // (tile 80 reduces its K slices inside the launch and keeps the column-sum stage under split-K)
+  if (d.stats && (d.store_mode != 0 || d.out_f32 || d.act == DBIR_ACT_GEGLU || (d.splitk > 1 && d.tile != 80) || d.batch > 1 ||
                   (reinterpret_cast<uintptr_t>(d.stats) & 15)))
     d.stats = nullptr;
   DBIR_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "dbir_gemm: bad M/N/K %d %d %d", d.M, d.N, d.K);
@@ -323,7 +328,13 @@ static int dbir_gemm_impl(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 92 && tile != 13 && !(tile >= 74 && tile <= 89), "dbir_gemm: bad tile %d", tile);
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 92 && tile != 13 && !(tile >= 74 && tile <= 89 && tile != 80), "dbir_gemm: bad tile %d", tile);
+  if (tile == 80) {
+    DBIR_CHECK_ARG(dbir_gemm_8p_eligible(d),
+                   "dbir_gemm: tile 80 (fine-phase 256x320 kernel) needs a linear / 3x3 convolution with K / Cin %% 32 == 0, "
+                   "16-byte aligned operands, a 16-bit row-major output and no GEGLU / transposed / f32 store / batch");
+    return dbir_gemm_8p(d, p.Hv, p.Wv, tile, reinterpret_cast<hipStream_t>(stream));
+  }
   if (tile >= 70 && tile < 80) {
     DBIR_CHECK_ARG(dbir_gemm_pers_eligible(d, tile),
                    "dbir_gemm: tile %d (persistent linear kernel) needs a dense linear with K %% 32 == 0, M a multiple of "

@@ -619,7 +619,7 @@ template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, 
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int RPP_ = 64 * (LDW ? LDW : WM * WN) / (BKT / 8), BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
-  constexpr int ring = STAGES * (BM + BNR) * BKT * 2, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
+  constexpr int ring = STAGES * (BM + BNR) * BKT * 2, epi = BM * (BN + 8) * 2 + 16 * BN;  // operand ring / transposed C tile + (bias + row vector) table
   constexpr int lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   constexpr int blocks_per_cu = (160 * 1024) / lds;

@@ -464,7 +464,7 @@ int dbir_splitk_reduce_launch(const dbir_gemm_desc& d, int splitk, float* ws, hi
 template <typename T, int WM, int WN, int MI, int NJ, int PMAX, int ABL = 0, int LS = 0>
 static int launch_halo(HParams& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-  constexpr int ring = 2 * (PMAX * 128 + 256) + 3 * BN * 128, epi = BM * (BN + 8) * 2;
+  constexpr int ring = 2 * (PMAX * 128 + 256) + 3 * BN * 128, epi = BM * (BN + 8) * 2 + 16 * BN;
   constexpr int lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   const dbir_gemm_desc& dd = p.d;

@@ -220,7 +220,12 @@ def apply_tile_code(d: GemmDesc, code: int, device) -> None:
     """code = tile id + 100 * split-K factor (diffbir_amd/tuning.py)."""
     d.tile, sk = code % 100, code // 100
     if sk > 1:
-        ws = splitk_workspace(device, sk * max(d.batch, 1) * d.M * d.N * 4)
+        if d.tile == 80:   # in-launch reduce: whole 256 x 320 accumulator slabs per (tile, slice) + arrival counters
+            tiles = ((d.M + 255) // 256) * ((d.N + 319) // 320)
+            nbytes = tiles * sk * 256 * 320 * 4 + tiles * 4 + 256
+        else:
+            nbytes = sk * max(d.batch, 1) * d.M * d.N * 4
+        ws = splitk_workspace(device, nbytes)
         d.splitk, d.ws, d.ws_bytes = sk, ws.data_ptr(), ws.numel() * 4
     else:
         d.splitk, d.ws, d.ws_bytes = 0, None, 0

@@ -589,7 +589,7 @@ def _check_partials(name, st, stored, rows_total):
     assert e1 < 2e-6 and e2 < 2e-6, f"{name}: column sums off by {e1:.2e} / {e2:.2e} (f32 accumulation of 16-bit values)"
 
 
-STATS_TILES = [0] + [t for t in GLDS_TILES] + [50, 51, 52, 53]
+STATS_TILES = [0] + [t for t in GLDS_TILES] + [50, 51, 52, 53, 80]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -641,6 +641,150 @@ def test_epilogue_group_norm_statistics(tile, dtype):
     if tile in (5, 12):
         _, none2 = ops.conv3x3(x, pc, tile=tile + 200, stats=True)
         assert none2 is None
+
+
+# ------------------------------------------------------------------------------------------------ fine-phase 256x320 kernel (tile 80)
+P8_LIN = [(1000, 320, 320), (130, 72, 64), (257, 200, 1024), (4096, 640, 2560), (3, 1280, 320), (513, 1288, 128),
+          (256, 320, 32), (512, 640, 96), (2048, 320, 4096)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", P8_LIN)
+def test_8p_linear(M, N, K, dtype):
+    """gemm_8p.hip (256x320 tile, K stages of 32, two staggered wave groups) against the unpacked f32 statement; stage
+    counts 1 .. 128 exercise the prologue (1-3 stages), the predicated tail and the steady-state loop."""
+    x = rnd(M, K, dtype=dtype)
+    w, b = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    got = ops.linear(x, pw, tile=80)
+    ref = (x.float() @ w.to(dtype).float().t() + b).to(dtype)
+    check(f"8p linear {M}x{N}x{K}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [emu.ACT_NONE, emu.ACT_SILU, emu.ACT_GELU, emu.ACT_LRELU])
+def test_8p_linear_epilogue(act, dtype):
+    M, N, K, rpb = 384, 200, 192, 96
+    x = rnd(M, K + 24, dtype=dtype)[:, :K]
+    w, b = rnd(N, K, dtype=torch.float32, s=K ** -0.5, seed=1), rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_linear(w.cpu(), b.cpu(), dtype, DEV)
+    res = rnd(M, N + 8, dtype=dtype, seed=3)[:, :N]
+    rv = rnd(M // rpb, N + 16, dtype=dtype, seed=4)[:, 8:8 + N]
+    out_a = torch.zeros(M, N + 40, dtype=dtype, device=DEV)
+    out_b = torch.zeros(M, N + 40, dtype=dtype, device=DEV)
+    kw = dict(act=act, act_param=0.2, out_scale=0.7, residual=res, rowvec=rv, rows_per_batch=rpb)
+    ops.linear(x, pw, out=out_a[:, 16:16 + N], tile=80, **kw)
+    emu.linear(x, pw, out=out_b[:, 16:16 + N], **kw)
+    check(f"8p linear epilogue act{act}", out_a, out_b, dtype, scale=1.5)
+
+
+P8_CONV = [c for c in GLDS_CONV_CASES] + [(2, 16, 16, 32, 64, 1, 1, False, None), (1, 12, 20, 96, 320, 1, 1, False, None),
+                                          (4, 64, 64, 320, 320, 1, 1, False, None), (2, 16, 16, 160, 96, 1, 1, True, None)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,N,stride,pad,ups,ohw", P8_CONV)
+def test_8p_conv3x3(B, H, W, Cin, N, stride, pad, ups, ohw, dtype):
+    x = rnd(B, H, W, Cin, dtype=dtype)
+    w = rnd(N, Cin, 3, 3, dtype=torch.float32, s=(9 * Cin) ** -0.5, seed=1)
+    b = rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_conv3x3(w.cpu(), b.cpu(), dtype, DEV)
+    got = ops.conv3x3(x, pw, tile=80, stride=stride, pad=pad, upsample=ups, out_hw=ohw)
+    xi = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xi = torch.nn.functional.interpolate(xi, scale_factor=2, mode="nearest")
+    if ohw is not None:
+        xi = torch.nn.functional.pad(xi, (0, 1, 0, 1))
+    ref = torch.nn.functional.conv2d(xi, w.to(dtype).float(), b, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    check(f"8p conv3x3 {B}x{H}x{W}x{Cin}->{N} s{stride} p{pad} u{int(ups)}", got, ref.to(dtype), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_8p_conv3x3_fused_epilogue_and_splitk(dtype):
+    """time-embedding row vector + strided residual into a concat-buffer view; split-K inside the launch (2 = own + other,
+    3 / 4 / 9 = all slabs in slice order; 40 clamps to the stage count): every code twice, bit-identical (deterministic)."""
+    B, H, W, Cin, N = 4, 16, 16, 256, 136
+    x = rnd(B, H, W, Cin, dtype=dtype)
+    pw = ops.pack_conv3x3(rnd(N, Cin, 3, 3, dtype=torch.float32, s=(9 * Cin) ** -0.5, seed=1).cpu(),
+                          rnd(N, dtype=torch.float32, seed=2).cpu(), dtype, DEV)
+    emb, res = rnd(B, N, dtype=dtype, seed=3), rnd(B, H, W, N + 32, dtype=dtype, seed=4)[..., 32:]
+    oa, ob = (torch.zeros((B, H, W, N + 24), dtype=dtype, device=DEV) for _ in range(2))
+    ops.conv3x3(x, pw, rowvec=emb, residual=res, out=oa[..., :N], tile=80)
+    emu.conv3x3(x, pw, rowvec=emb, residual=res, out=ob[..., :N])
+    check("8p conv3x3 emb+res into concat view", oa, ob, dtype, scale=1.5)
+    kw = dict(rowvec=emb, residual=res, act=emu.ACT_SILU, out_scale=0.7)
+    ref = emu.conv3x3(x, pw, **kw)
+    for sk in (2, 3, 4, 9, 40):
+        code = 80 + 100 * sk
+        got = ops.conv3x3(x, pw, tile=code, **kw).clone()
+        check(f"8p splitk code {code}", got, ref, dtype, scale=1.5)
+        for _ in range(3):
+            assert torch.equal(got, ops.conv3x3(x, pw, tile=code, **kw)), f"split-K {sk} is not deterministic"
+    # split-K keeps the GroupNorm column sums (the last arriver holds the whole tile)
+    o2, st = ops.conv3x3(x, pw, tile=280, stats=True, **kw)
+    assert st is not None and st.rows == 256
+    _check_partials("8p split-K stats", st, o2, B * H * W)
+    # linear, ragged M, strided output view
+    xl = rnd(300, 192, dtype=dtype, seed=5)
+    pl = ops.pack_linear(rnd(136, 192, dtype=torch.float32, s=0.07, seed=6).cpu(), rnd(136, dtype=torch.float32, seed=7).cpu(),
+                         dtype, DEV)
+    oa = torch.zeros(300, 160, dtype=dtype, device=DEV)
+    ob = torch.zeros_like(oa)
+    ops.linear(xl, pl, out=oa[:, 8:144], tile=380)
+    emu.linear(xl, pl, out=ob[:, 8:144])
+    check("8p splitk linear", oa, ob, dtype, scale=1.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_8p_race_screen(dtype):
+    """Tile 80 at full-chip sizes, repeated, against the 2-stage 128x128 kernel (tile 5): same 16-k MFMA steps; the K
+    visiting order differs (32-channel slices), so allow a few ulp — a staging race corrupts whole stages."""
+    cases = []
+    x = rnd(16, 64, 64, 320, dtype=dtype)
+    pw = ops.pack_conv3x3(rnd(320, 320, 3, 3, dtype=torch.float32, s=0.02, seed=1).cpu(),
+                          rnd(320, dtype=torch.float32, seed=2).cpu(), dtype, DEV)
+    emb = rnd(16, 320, dtype=dtype, seed=3)
+    cases.append(("conv 16x64x64 320->320 +emb", lambda t: ops.conv3x3(x, pw, rowvec=emb, tile=t)))
+    x2 = rnd(16, 16, 16, 1280, dtype=dtype, seed=4)
+    pw2 = ops.pack_conv3x3(rnd(1280, 1280, 3, 3, dtype=torch.float32, s=0.01, seed=5).cpu(), None, dtype, DEV)
+    cases.append(("conv 16x16x16 1280->1280 k4", lambda t: ops.conv3x3(x2, pw2, tile=t + (400 if t == 80 else 0))))
+    x3 = rnd(16384, 2560, dtype=dtype, seed=6)
+    pw3 = ops.pack_linear(rnd(640, 2560, dtype=torch.float32, s=0.02, seed=7).cpu(), None, dtype, DEV)
+    # (no residual here: out = round(round(acc) + res) turns a 1-ulp difference of the large intermediate into many
+    #  ulp of a small result — the residual path is covered by the epilogue tests)
+    cases.append(("linear 16384x640x2560 k2", lambda t: ops.linear(x3, pw3, tile=t + (200 if t == 80 else 0))))
+    x5 = rnd(8, 33, 47, 64, dtype=dtype, seed=12)
+    pw5 = ops.pack_conv3x3(rnd(200, 64, 3, 3, dtype=torch.float32, s=0.05, seed=13).cpu(), None, dtype, DEV)
+    cases.append(("conv 8x33x47 64->200 s2", lambda t: ops.conv3x3(x5, pw5, stride=2, tile=t)))
+    ulp = 4 * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
+    for name, fn in cases:
+        ref = fn(5).clone().float()
+        floor = 2.0 ** -12 * ref.abs().max().item()
+        first = None
+        for it in range(6):
+            got = fn(80)
+            if first is None:
+                first = got.clone()
+            assert torch.equal(got, first), f"{name}: tile 80 differs between repetitions (iteration {it})"
+            bad = (got.float() - ref).abs() > ulp * ref.abs() + floor
+            assert not bad.any(), f"{name}: tile 80 differs from tile 5 (iteration {it}): " \
+                f"{(got.float() - ref).abs().max().item():.3e} max abs, {bad.float().mean().item():.2e} of the elements"
+
+
+def test_8p_rejects_ineligible():
+    dtype = torch.float16
+    pw = ops.pack_linear(rnd(320, 320, dtype=torch.float32, s=0.05, seed=1).cpu(), None, dtype, DEV)
+    with pytest.raises(Exception):                                     # transposed store
+        ops.linear_t(rnd(1024, 320, dtype=dtype), pw, 512, torch.zeros(2, 320, 512, dtype=dtype, device=DEV), tile=80)
+    with pytest.raises(Exception):                                     # f32 output
+        ops.linear(rnd(1024, 320, dtype=dtype), pw, out_f32=True, tile=80)
+    pg = ops.pack_geglu(rnd(640, 320, dtype=torch.float32, s=0.05, seed=2).cpu(), rnd(640, dtype=torch.float32, seed=3).cpu(),
+                        dtype, DEV)
+    with pytest.raises(Exception):                                     # GEGLU
+        ops.linear(rnd(1024, 320, dtype=dtype), pg, tile=80)
+    pc = ops.pack_conv3x3(rnd(64, 40, 3, 3, dtype=torch.float32, s=0.05, seed=1).cpu(), None, dtype, DEV)
+    with pytest.raises(Exception):                                     # Cin % 32 != 0
+        ops.conv3x3(rnd(2, 16, 16, 40, dtype=dtype), pc, tile=80)
 
 
 # ------------------------------------------------------------------------------------------------ fused transformer block
