@@ -8,6 +8,10 @@ validated against the default kernel's output, timed (min of 4 HIP-event timings
 is kept in `~/.cache/diffbir_amd/tuning_<device>.json` for later processes.  One key costs ~10 - 30 ms once; a new image
 shape has ~100 keys.
 
+The cache file carries the library's ABI version + candidate tile set (a mismatch discards it), keys include the element
+type, and an entry `dbir_gemm` rejects is evicted.  Timing-based choices are not bit-reproducible across processes / ranks
+(two tiles sum in different orders): set DBIR_AUTOTUNE=0 where bit-identical outputs across runs matter (the tests do).
+
 Off: DBIR_AUTOTUNE=0.  Never runs while a HIP graph is being captured, for in-place residual launches (re-running would
 accumulate), or for launches too small to matter (< 0.5 GFLOP).  Correctness never depends on it: every candidate's
 output is compared with the default kernel's, and `dbir_gemm` refuses tiles a shape cannot run.
@@ -24,8 +28,8 @@ from . import native, tuning
 
 ENABLED = os.environ.get("DBIR_AUTOTUNE", "1") != "0" and os.environ.get("DBIR_TUNING", "1") != "0"
 MIN_FLOPS = 0.5e9
-GENERIC = [5, 10, 14, 15, 25, 30, 34, 36, 37, 44, 45, 50, 52, 70, 71, 72, 73]
-ALWAYS = [14, 15, 25, 36, 37, 50, 52, 70, 71, 72, 73]
+GENERIC = [5, 10, 14, 15, 25, 30, 34, 36, 37, 44, 45, 50, 52, 70, 71, 72, 73, 80, 280, 480]
+ALWAYS = [14, 15, 25, 36, 37, 50, 52, 70, 71, 72, 73, 80, 280, 480]
 # (the producer / consumer tiles 90 - 92 win 5 - 15 % on K >= 1280 linears timed alone and nothing / -2 % in the two-stream
 # evaluation, profiles/r3_pc_tiles_ab.txt: they are not offered to the timing-based choice)   # added behind a class's own winners (dbir_gemm refuses misfits)
 _cache: Optional[Dict[str, int]] = None
@@ -34,6 +38,28 @@ _dirty = False
 _class_cands: Dict[str, List[int]] = {}
 _class_src = None
 stats = dict(tuned=0, hits=0, us_spent=0.0)
+
+
+def _signature() -> str:
+    """What a cached winner depends on besides the problem key: the library's ABI version and the candidate tile set
+    (tiles were added and retired between builds; a stale entry made every such launch fail and retry)."""
+    try:
+        abi = int(native.lib().dbir_abi_version())
+    except Exception:  # noqa: BLE001 - no library (CPU-only process): the cache is never consulted for a launch anyway
+        abi = -1
+    return f"abi{abi}:" + ",".join(str(t) for t in sorted(set(GENERIC + ALWAYS)))
+
+
+def cache_key(d) -> str:
+    """tuning.key_of + the element type (f16 and bf16 winners differ: the matrix pipe clocks differently)."""
+    return f"{tuning.key_of(d)}:d{d.dtype}"
+
+
+def evict(key: str) -> None:
+    """Drop an entry `dbir_gemm` rejected (ops._gemm_launch): the next launch of the key is tuned again."""
+    global _dirty
+    if _cache is not None and _cache.pop(key, None) is not None:
+        _dirty = True
 
 
 def _path() -> str:
@@ -51,7 +77,9 @@ def _load() -> Dict[str, int]:
         _cache = {}
         try:
             with open(_cache_path) as f:
-                _cache = {k: int(v) for k, v in json.load(f).get("tiles", {}).items()}
+                raw = json.load(f)
+            if raw.get("signature") == _signature():   # otherwise: another library / tile set wrote it -> start over
+                _cache = {k: int(v) for k, v in raw.get("tiles", {}).items()}
         except (OSError, ValueError):
             pass
         atexit.register(save)
@@ -66,7 +94,7 @@ def save() -> None:
         os.makedirs(os.path.dirname(_cache_path), exist_ok=True)
         tmp = _cache_path + f".{os.getpid()}.tmp"
         with open(tmp, "w") as f:
-            json.dump(dict(tiles=_cache), f, indent=0, sort_keys=True)
+            json.dump(dict(signature=_signature(), tiles=_cache), f, indent=0, sort_keys=True)
         os.replace(tmp, _cache_path)
         _dirty = False
     except OSError:
@@ -116,6 +144,7 @@ def tune(d, out: torch.Tensor, apply_tile_code) -> Optional[int]:
     if 2.0 * d.M * d.N * d.K * max(d.batch, 1) < MIN_FLOPS:
         return None
     key = tuning.key_of(d)
+    ckey = cache_key(d)
     lib, st = native.lib(), torch.cuda.current_stream().cuda_stream
 
     def timed(iters=4):
@@ -156,7 +185,7 @@ def tune(d, out: torch.Tensor, apply_tile_code) -> Optional[int]:
     best = min(us, key=lambda k: us[k])
     if us[best] > 0.97 * us[0]:
         best = 0
-    _load()[key] = int(best)
+    _load()[ckey] = int(best)
     _dirty = True
     stats["tuned"] += 1
     stats["us_spent"] += sum(v for v in us.values() if v) * 5

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   // diagnostic variants (P8_VARIANTS builds only; timing, results meaningless for 4 / 8 / 16)
   constexpr bool NOPRIO = (VAR & 2) != 0, NOMFMA = (VAR & 4) != 0, NOSTAGE = (VAR & 8) != 0, NOREAD = (VAR & 16) != 0;
   constexpr bool TIMING = (VAR & 32) != 0, LGK_EARLY = (VAR & 64) != 0;
+  constexpr bool ONEBAR = (VAR & 128) != 0;       // one-barrier-per-phase schedule (see the ONEBAR block of the main loop)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const unsigned long long rt_kernel = TIMING ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   WAIT_NEXT(nst > 1, nst > 2);   // stage 0 landed (this wave's share)
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_barrier" ::: "memory");
-  if (grp == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one barrier behind group 0
+  if (!ONEBAR && grp == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one barrier behind group 0
 
   const int a_frag = (wm * 32 * MI + lq) * ROWB;
   const int b_frag = A_BYTES + (wn * 32 * NJ + lq) * ROWB;
@@ -329,8 +330,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   if (TIMING) t_prev = __builtin_amdgcn_s_memtime();
   const unsigned long long t_start = t_prev;
   const unsigned long long rt_start = TIMING ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz reference clock
-  // steady state: every stage of the iteration still has three successors -> no predicates, literal wait counts
   int st = 0;
+  if constexpr (!ONEBAR) {
+  // steady state: every stage of the iteration still has three successors -> no predicates, literal wait counts
   for (; st + 7 <= nst; st += 4) {
     STAGE2(0, st, 1);
     STAGE2(1, st + 1, 1);
@@ -345,6 +347,116 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   if (st + 4 < nst) STAGE2(0, st + 4, 0);
   if (st + 5 < nst) STAGE2(1, st + 5, 0);
   if (grp == 0) asm volatile("s_barrier" ::: "memory");  // pairs group 1's extra barrier
+  } else {
+  // ---- ONEBAR: ONE workgroup barrier per phase.  Between barriers k and k + 1 group 0 runs [M(k) ; R(k + 1)] and group 1
+  // runs [R(k) ; M(k)]: the first half of the interval is M0 || R1, the second R0 || M1 — the same complementary pairing as
+  // above with half the barriers (the pairing inside an interval is by equal section lengths, not enforced).
+  //   RAW: "stage s landed" is waited for in front of barrier 2s - 1 by every wave (group 0 in its R(s - 1, 1), which runs
+  //        in interval 2s - 2; group 1 behind its M(s - 1, 0), same interval); the first read of stage s is group 0's R(s, 0)
+  //        in interval 2s - 1.
+  //   WAR: B(s + 2) -> slot of stage s - 2, last read by group 1 in interval 2s - 3, issued in interval 2s - 1 (group 0) /
+  //        2s (group 1); A(s + 3) -> slot of stage s - 1, last read by group 1 in interval 2s - 1 (retired before its MFMAs),
+  //        issued in interval 2s (group 0) / 2s + 1 (group 1).
+#define RPART(Q, KS, S, FULL, G)                                                                            \
+  do {                                                                                                      \
+    {                                                                                                       \
+      const char* base_ = smem + (Q) * SLOT + ((KS) ? co1 : co0);                                           \
+      _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_) wf[j_] =                                            \
+          *reinterpret_cast<const typename T::vec8*>(base_ + b_frag + j_ * FSTR);                           \
+      _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) xf[i_] =                                            \
+          *reinterpret_cast<const typename T::vec8*>(base_ + a_frag + i_ * FSTR);                           \
+    }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if ((KS) == 0) {                                                                                        \
+      if ((FULL) || (S) + 2 < nst) ISSUE_B(((Q) + 2) & 3);                                                  \
+    } else {                                                                                                \
+      if ((FULL) || (S) + 3 < nst) ISSUE_A(((Q) + 3) & 3);                                                  \
+      if ((G) == 0) {                                                                                       \
+        if (FULL) wait_vm8<7>();                                                                            \
+        else if ((S) + 1 < nst) { if ((S) + 3 < nst) wait_vm8<7>(); else if ((S) + 2 < nst) wait_vm8<5>(); else wait_vm8<0>(); } \
+      }                                                                                                     \
+    }                                                                                                       \
+    TS(t_r);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+  } while (0)
+#define MPART()                                                                                             \
+  do {                                                                                                      \
+    if (!NOPRIO) __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                                       \
+      _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_)                                                     \
+        acc[i_][j_] = T::mfma32(wf[j_], xf[i_], acc[i_][j_]); /* D[n][m] */                                 \
+    if (!NOPRIO) __builtin_amdgcn_s_setprio(0);                                                             \
+    TS(t_m);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+  } while (0)
+#define BAR1()                                   \
+  do {                                           \
+    __builtin_amdgcn_sched_barrier(0);           \
+    asm volatile("s_barrier" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);           \
+    TS(t_b1);                                    \
+  } while (0)
+// group 1, behind M(s, 0): its share of stage s + 1 landed (only B(s + 2), issued in this phase, may stay in flight: LB = 2
+// for this group, plus A(s + 2) issued one phase earlier: LA + LB = 4)
+#define WAIT_G1(S, FULL)                                                      \
+  do {                                                                        \
+    if (FULL) wait_vm8<4>();                                                  \
+    else if ((S) + 1 < nst) { if ((S) + 2 < nst) wait_vm8<4>(); else wait_vm8<0>(); } \
+  } while (0)
+    if (grp == 0) {
+      RPART(0, 0, 0, 0, 0);
+#define G0_STAGE(Q, S, FULL)                                         \
+  do {                                                               \
+    BAR1();                                                          \
+    MPART();                                                         \
+    RPART(Q, 1, S, FULL, 0);                                         \
+    BAR1();                                                          \
+    MPART();                                                         \
+    if ((FULL) || (S) + 1 < nst) RPART(((Q) + 1) & 3, 0, (S) + 1, FULL, 0); \
+  } while (0)
+      for (; st + 7 <= nst; st += 4) {
+        G0_STAGE(0, st, 1);
+        G0_STAGE(1, st + 1, 1);
+        G0_STAGE(2, st + 2, 1);
+        G0_STAGE(3, st + 3, 1);
+      }
+      if (st < nst) G0_STAGE(0, st, 0);
+      if (st + 1 < nst) G0_STAGE(1, st + 1, 0);
+      if (st + 2 < nst) G0_STAGE(2, st + 2, 0);
+      if (st + 3 < nst) G0_STAGE(3, st + 3, 0);
+      if (st + 4 < nst) G0_STAGE(0, st + 4, 0);
+      if (st + 5 < nst) G0_STAGE(1, st + 5, 0);
+#undef G0_STAGE
+    } else {
+#define G1_STAGE(Q, S, FULL)        \
+  do {                              \
+    BAR1();                         \
+    RPART(Q, 0, S, FULL, 1);        \
+    MPART();                        \
+    WAIT_G1(S, FULL);               \
+    BAR1();                         \
+    RPART(Q, 1, S, FULL, 1);        \
+    MPART();                        \
+  } while (0)
+      for (; st + 7 <= nst; st += 4) {
+        G1_STAGE(0, st, 1);
+        G1_STAGE(1, st + 1, 1);
+        G1_STAGE(2, st + 2, 1);
+        G1_STAGE(3, st + 3, 1);
+      }
+      if (st < nst) G1_STAGE(0, st, 0);
+      if (st + 1 < nst) G1_STAGE(1, st + 1, 0);
+      if (st + 2 < nst) G1_STAGE(2, st + 2, 0);
+      if (st + 3 < nst) G1_STAGE(3, st + 3, 0);
+      if (st + 4 < nst) G1_STAGE(0, st + 4, 0);
+      if (st + 5 < nst) G1_STAGE(1, st + 5, 0);
+#undef G1_STAGE
+    }
+#undef RPART
+#undef MPART
+#undef BAR1
+#undef WAIT_G1
+  }
   if (TIMING && p.ws && lane == 0 && p.splitk <= 1) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + ((long long)blockIdx.x * 8 + wave) * 8;
     o[0] = t_r; o[1] = t_b1; o[2] = t_m; o[3] = t_b2;
@@ -434,9 +546,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   const int ncol = tn * BN + ch * 8;
   const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) : nullptr;
   u16* __restrict__ Cg = reinterpret_cast<u16*>(d.C);
-  float s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  ColStat cstat;
+  colstat_init(cstat);
   const bool want_stats = d.stats != nullptr;
   const bool streamer = rl < RL && ncol < N;
   const bool full_chunk = ncol + 8 <= N;
@@ -536,25 +647,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_srd, (trow * (int)d.ldc + ncol) * 2, 0, 0);
           if (want_stats && m < M) {
             unpack8<T>(v, a);  // statistics of what was stored (16-bit rounded)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              s1[e] += a[e];
-              s2[e] += a[e] * a[e];
-            }
+            colstat_add(cstat, a);
           }
         } else if (m < M) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
+            float x = a[e];
             if (ncol + e < N) {
-              float x = a[e];
               if (Rg) x += T::to_f32(Rg[(long long)m * d.ldr + ncol + e]);
               const u16 hv = T::from_f32(x);
               Cg[(long long)m * d.ldc + ncol + e] = hv;
               x = T::to_f32(hv);
-              s1[e] += x;
-              s2[e] += x * x;
             }
+            a[e] = x;
           }
+          if (want_stats) colstat_add(cstat, a);
         }
       }
     }
@@ -572,27 +679,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
     o[3] = rt_e1 - rt_e0;      // pass 0 (its stores issued)
     o[4] = rt_e2 - rt_e1;      // pass 1 + store drain
   }
-  if (want_stats) {
-    __syncthreads();
-    float* ps = reinterpret_cast<float*>(smem);
-    if (rl < RL) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        ps[(rl * CPR + ch) * 16 + e] = s1[e];
-        ps[(rl * CPR + ch) * 16 + 8 + e] = s2[e];
-      }
-    }
-    __syncthreads();
-    float* __restrict__ stp = d.stats + (long long)tm * 2 * N;
-    for (int c = tid; c < 2 * BN; c += 512) {
-      const int which = c / BN, col = c - which * BN, n = tn * BN + col;
-      if (n < N) {
-        float a = 0.f;
-        for (int r = 0; r < RL; ++r) a += ps[(r * CPR + (col >> 3)) * 16 + which * 8 + (col & 7)];
-        stp[which * N + n] = a;
-      }
-    }
-  }
+  if (want_stats)
+    colstat_finish<512, BN, CPR, RL>(cstat, streamer, smem, tid, ch, rl, d.stats + (long long)tm * 2 * N, tn, N);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -701,6 +789,9 @@ int dbir_gemm_8p(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream_t
         case 64: return launch_8p<F16, 64>(p, s);
         case 66: return launch_8p<F16, 66>(p, s);
         case 12: return launch_8p<F16, 12>(p, s);
+        case 128: return launch_8p<F16, 128>(p, s);
+        case 130: return launch_8p<F16, 130>(p, s);
+        case 160: return launch_8p<F16, 160>(p, s);
         case 20: return launch_8p<F16, 20>(p, s);
       }
     }

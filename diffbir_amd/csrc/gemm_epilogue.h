@@ -28,6 +28,73 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
+
+// ---- GroupNorm column statistics of the STORED tile (dbir_gemm_desc.stats) -------------------------------------------------
+// Per (row tile, column): stats[tile][0][n] = sum of the stored values, stats[tile][1][n] = M2 = sum of squared deviations
+// from that tile-column's own mean.  A thread accumulates its rows SHIFTED by its first value (no cancellation when
+// |mean| >> sigma: ADVICE round 3), the row lanes of a column are merged pairwise (Chan et al.) in a fixed order through
+// LDS: deterministic, and the consumer (gn_from_partials) merges tiles the same way in f64.
+struct ColStat {
+  float piv[8], s1[8], s2[8];
+  int cnt;
+};
+__device__ __forceinline__ void colstat_init(ColStat& c) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c.piv[e] = c.s1[e] = c.s2[e] = 0.f;
+  c.cnt = 0;
+}
+__device__ __forceinline__ void colstat_add(ColStat& c, const float* a) {
+  if (c.cnt == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c.piv[e] = a[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float dlt = a[e] - c.piv[e];
+    c.s1[e] += dlt;
+    c.s2[e] += dlt * dlt;
+  }
+  ++c.cnt;
+}
+// CPR chunks of 8 columns per tile row, RL row lanes (thread (ch, rl) walked rows rl, rl + RL, ...); `active` = the thread
+// took part; smem: the block's LDS (>= RL * CPR * 68 bytes, nothing else live); NT threads call this together.
+template <int NT, int BN, int CPR, int RL>
+__device__ __forceinline__ void colstat_finish(const ColStat& c, bool active, char* smem, int tid, int ch, int rl,
+                                               float* __restrict__ st, int tn, int N) {
+  __syncthreads();
+  float* ps = reinterpret_cast<float*>(smem);          // [RL * CPR][16]: mean[8] | M2[8]
+  int* pc = reinterpret_cast<int*>(smem + RL * CPR * 64);  // [RL * CPR]: rows accumulated
+  if (rl < RL) {
+    const int slot = rl * CPR + ch;
+    const int n = active ? c.cnt : 0;
+    const float inv = n > 0 ? 1.0f / (float)n : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ps[slot * 16 + e] = c.piv[e] + c.s1[e] * inv;
+      ps[slot * 16 + 8 + e] = c.s2[e] - c.s1[e] * c.s1[e] * inv;
+    }
+    pc[slot] = n;
+  }
+  __syncthreads();
+  for (int col = tid; col < BN; col += NT) {
+    const int n = tn * BN + col;
+    if (n >= N) continue;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int r = 0; r < RL; ++r) {
+      const int slot = r * CPR + (col >> 3);
+      const float nr = (float)pc[slot];
+      if (nr == 0.f) continue;
+      const float mr = ps[slot * 16 + (col & 7)], qr = ps[slot * 16 + 8 + (col & 7)];
+      const float tot = cnt + nr, dlt = mr - mean;
+      mean += dlt * (nr / tot);
+      m2 += qr + dlt * dlt * (cnt * nr / tot);
+      cnt = tot;
+    }
+    st[n] = mean * cnt;
+    st[N + n] = m2 > 0.f ? m2 : 0.f;
+  }
+}
+
 template <typename T, int WM, int WN, int MI, int NJ>
 __device__ __forceinline__ void gemm_epilogue(const dbir_gemm_desc& d, const EpiParams& p, f32x16 (&acc)[MI][NJ],
                                               char* smem, int tm, int tn, int ksp, int bz, int wm, int wn, int tid) {
@@ -190,9 +257,8 @@ __device__ __forceinline__ void gemm_epilogue(const dbir_gemm_desc& d, const Epi
       }
     }
     __syncthreads();
-    float s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    ColStat cs;
+    colstat_init(cs);
     const bool want_stats = d.stats != nullptr;
     if (streamer) {
 #pragma unroll
@@ -213,51 +279,26 @@ __device__ __forceinline__ void gemm_epilogue(const dbir_gemm_desc& d, const Epi
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), c_srd, (row * (int)d.ldc + ncol) * 2, 0, 0);
           if (want_stats && m < M) {
             unpack8<T>(v, a);  // statistics of what was stored (16-bit rounded)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              s1[e] += a[e];
-              s2[e] += a[e] * a[e];
-            }
+            colstat_add(cs, a);
           }
         } else if (m < M) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
+            float x = a[e];
             if (ncol + e < N) {
-              float x = a[e];
               if (Rg) x += T::to_f32(Rg[(long long)m * d.ldr + ncol + e]);
               const u16 hv = T::from_f32(x);
               Cg[(long long)m * d.ldc + ncol + e] = hv;
               x = T::to_f32(hv);
-              s1[e] += x;
-              s2[e] += x * x;
             }
+            a[e] = x;
           }
+          if (want_stats) colstat_add(cs, a);
         }
       }
     }
-    if (want_stats) {
-      // every column of the tile gets its two numbers: stats[tm][0][n] = sum, stats[tm][1][n] = sum of squares over the
-      // tile's BM rows; the RL row lanes are combined through LDS in a fixed order (deterministic)
-      __syncthreads();
-      float* ps = reinterpret_cast<float*>(smem);
-      if (rl < RL) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ps[(rl * CPR + ch) * 16 + e] = s1[e];
-          ps[(rl * CPR + ch) * 16 + 8 + e] = s2[e];
-        }
-      }
-      __syncthreads();
-      float* __restrict__ st = d.stats + (long long)tm * 2 * N;
-      for (int c = tid; c < 2 * BN; c += NT) {
-        const int which = c / BN, col = c - which * BN, n = tn * BN + col;
-        if (n < N) {
-          float a = 0.f;
-          for (int r = 0; r < RL; ++r) a += ps[(r * CPR + (col >> 3)) * 16 + which * 8 + (col & 7)];
-          st[which * N + n] = a;
-        }
-      }
-    }
+    if (want_stats)
+      colstat_finish<NT, BN, CPR, RL>(cs, streamer, smem, tid, ch, rl, d.stats + (long long)tm * 2 * N, tn, N);
     return;
   }
   // ---------------- GEGLU / transposed store: f32 math in registers -> 16-bit tile in LDS -> row-contiguous 16 B stores ----------
@@ -374,75 +415,7 @@ __device__ __forceinline__ void gemm_epilogue(const dbir_gemm_desc& d, const Epi
     }
     return;
   }
-  if (d.stats) {
-    // ---- store + GroupNorm column sums of the STORED values (host side: no GEGLU, M % BM == 0, one z slice) --------------
-    // a thread keeps ONE 8-column chunk and walks the tile's rows with stride RL, so its 8 sums / 8 sums of squares stay
-    // in registers; the RL row lanes are then combined through LDS in a fixed order (deterministic) and every column of
-    // the tile gets its two numbers: stats[tm][0][n] = sum, stats[tm][1][n] = sum of squares over the tile's BM rows.
-    constexpr int CPR = BN / 8, RL = NT / CPR;
-    const int ch = tid % CPR, rl = tid / CPR;
-    const int ncol = tn * BN + ch * 8;
-    const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) : nullptr;
-    u16* __restrict__ Cg = reinterpret_cast<u16*>(d.C);
-    float s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    if (rl < RL && ncol < N) {
-      for (int row = rl; row < BM; row += RL) {
-        const int m = tm * BM + row;
-        float a[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(Cs + row * cs_ld + ch * 8), a);
-        if (ncol + 8 <= N) {
-          if (Rg) {
-            float b[8];
-            unpack8<T>(*reinterpret_cast<const uint4*>(Rg + (long long)m * d.ldr + ncol), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += b[e];
-          }
-          const uint4 v = pack8<T>(a);
-          *reinterpret_cast<uint4*>(Cg + (long long)m * d.ldc + ncol) = v;
-          unpack8<T>(v, a);  // statistics of what was stored (16-bit rounded)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[e] += a[e];
-            s2[e] += a[e] * a[e];
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if (ncol + e < N) {
-              float x = a[e];
-              if (Rg) x += T::to_f32(Rg[(long long)m * d.ldr + ncol + e]);
-              const u16 hv = T::from_f32(x);
-              Cg[(long long)m * d.ldc + ncol + e] = hv;
-              x = T::to_f32(hv);
-              s1[e] += x;
-              s2[e] += x * x;
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();  // every read of the staged tile is done: reuse its LDS for the row-lane partials
-    float* ps = reinterpret_cast<float*>(smem);
-    if (rl < RL) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        ps[(rl * CPR + ch) * 16 + e] = s1[e];
-        ps[(rl * CPR + ch) * 16 + 8 + e] = s2[e];
-      }
-    }
-    __syncthreads();
-    float* __restrict__ st = d.stats + (long long)tm * 2 * N;
-    for (int c = tid; c < 2 * BN; c += NT) {
-      const int which = c / BN, col = c - which * BN, n = tn * BN + col;
-      if (n < N) {
-        float a = 0.f;
-        for (int r = 0; r < RL; ++r) a += ps[(r * CPR + (col >> 3)) * 16 + which * 8 + (col & 7)];
-        st[which * N + n] = a;
-      }
-    }
-  } else {
+  {
     const int n_out = geglu ? N / 2 : N;
     const int ch_per_row = bn_out >> 3;
     const int total = BM * ch_per_row;

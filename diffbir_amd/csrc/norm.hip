@@ -419,25 +419,29 @@ __global__ __launch_bounds__(256) void gn_from_partials(const float* __restrict_
   if (g >= groups) return;
   const int C = N1 + N2, cpg = C / groups, tiles = HW / rows;
   const int cells = tiles * cpg;
-  double s = 0.0, q = 0.0;
+  // cell = (tile, channel): n = rows values with sum s_i and M2_i (squared deviations from the cell's own mean).  Pass 1:
+  // the group mean; pass 2: M2 = sum_i [ M2_i + n (mean_i - mean)^2 ] — no difference of large numbers anywhere.
+  double s = 0.0;
   for (int idx = lane; idx < cells; idx += 64) {
     const int ti = idx / cpg, c = g * cpg + (idx - ti * cpg);
     const long long tile = (long long)b * tiles + ti;
-    if (c < N1) {
-      s += p1[tile * 2 * N1 + c];
-      q += p1[tile * 2 * N1 + N1 + c];
-    } else {
-      s += p2[tile * 2 * N2 + (c - N1)];
-      q += p2[tile * 2 * N2 + N2 + (c - N1)];
-    }
+    s += c < N1 ? p1[tile * 2 * N1 + c] : p2[tile * 2 * N2 + (c - N1)];
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o, 64);
-    q += __shfl_xor(q, o, 64);
-  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const double n = (double)HW * cpg, mean = s / n;
-  double var = q / n - mean * mean;
+  double q = 0.0;
+  for (int idx = lane; idx < cells; idx += 64) {
+    const int ti = idx / cpg, c = g * cpg + (idx - ti * cpg);
+    const long long tile = (long long)b * tiles + ti;
+    const double si = c < N1 ? p1[tile * 2 * N1 + c] : p2[tile * 2 * N2 + (c - N1)];
+    const double qi = c < N1 ? p1[tile * 2 * N1 + N1 + c] : p2[tile * 2 * N2 + N2 + (c - N1)];
+    const double dm = si / rows - mean;
+    q += qi + dm * dm * rows;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  double var = q / n;
   var = var > 0.0 ? var : 0.0;
   if (mean_var && lane == 0) {
     mean_var[(long long)b * 2 * groups + g] = (float)mean;

@@ -843,20 +843,28 @@ int xf_launch_tail(int dtype, int stop_after, int grid, hipStream_t s, const XfP
   static bool attr_set = false;
   if (!attr_set) {
     if (xf_set_lds(&xf_tail_kernel<F16, 0, CC>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 0, CC>) != 0 ||
-        xf_set_lds(&xf_tail_kernel<F16, 1, CC>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 1, CC>) != 0 ||
-        xf_set_lds(&xf_tail_kernel<F16, 2, CC>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 3, CC>) != 0 ||
-        xf_set_lds(&xf_tail_kernel<F16, 4, CC>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 5, CC>) != 0) {
+        xf_set_lds(&xf_tail_kernel<F16, 1, CC>) != 0 || xf_set_lds(&xf_tail_kernel<BF16, 1, CC>) != 0
+#ifdef DBIR_DIAG
+        || xf_set_lds(&xf_tail_kernel<F16, 2, CC>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 3, CC>) != 0 ||
+        xf_set_lds(&xf_tail_kernel<F16, 4, CC>) != 0 || xf_set_lds(&xf_tail_kernel<F16, 5, CC>) != 0
+#endif
+    ) {
       dbir_set_error("dbir_xf_tail: cannot reserve %d bytes of LDS", XF_LDS);
       return DBIR_ERR_LAUNCH;
     }
     attr_set = true;
   }
   if (stop_after >= 99) {  // section timing (99) / ablations (103 - 105), f16 only, results meaningless
+#ifdef DBIR_DIAG           // only in a `DBIR_DIAG=1 sh build.sh` library (tools/xf_anatomy.py), never in the production ABI
     DBIR_CHECK_ARG(dtype == DBIR_F16, "dbir_xf_tail: the timing instantiations are f16 only");
     if (stop_after == 99) hipLaunchKernelGGL((xf_tail_kernel<F16, 2, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
     else if (stop_after == 103) hipLaunchKernelGGL((xf_tail_kernel<F16, 3, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
     else if (stop_after == 104) hipLaunchKernelGGL((xf_tail_kernel<F16, 4, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
     else hipLaunchKernelGGL((xf_tail_kernel<F16, 5, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
+#else
+    dbir_set_error("dbir_xf_tail: stop_after %d (timing / ablation instantiations) needs a DBIR_DIAG build", stop_after);
+    return DBIR_ERR_ARG;
+#endif
   } else if (stop_after) {  // debug instantiation (tests): intermediate dumps
     if (dtype == DBIR_F16) hipLaunchKernelGGL((xf_tail_kernel<F16, 1, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
     else hipLaunchKernelGGL((xf_tail_kernel<BF16, 1, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);

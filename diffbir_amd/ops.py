@@ -240,7 +240,7 @@ def _gemm_launch(d: GemmDesc, keep):
         else:
             code = tuning.lookup_exact(d)
             if code is None:   # not in the shipped table: this device's first-use autotune cache, tuned on a miss
-                key = tuning.key_of(d)
+                key = autotune.cache_key(d)
                 code = autotune.lookup(key)
                 if code is None:
                     code = autotune.tune(d, out, apply_tile_code)
@@ -262,6 +262,7 @@ def _gemm_launch(d: GemmDesc, keep):
     with _Timed("gemm", 2.0 * d.M * (d.N) * d.K * z, tag, nbytes):
         rc = native.lib().dbir_gemm(ctypes.byref(d), _stream())
         if rc != 0 and from_table:  # a tuned variant whose alignment requirements this call does not meet
+            autotune.evict(autotune.cache_key(d))
             apply_tile_code(d, 0, out.device)
             rc = native.lib().dbir_gemm(ctypes.byref(d), _stream())
         native.check(rc, "dbir_gemm")

@@ -249,6 +249,11 @@ def run_hybrid(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise_fo
     if noise_for_image is None:
         noise_for_image = lambda i: ShardedNoise.seeded(231 + i, ctx.device)  # noqa: E731
     prev = pipe.randn
+    # the sharding state the pipeline / its VAE had before this call comes back afterwards: a later
+    # pipe.run or run_data_parallel on the same pipeline must not all-reduce over this call's sub-group
+    vae = getattr(getattr(pipe, "cldm", None), "vae", None)
+    saved = (getattr(pipe, "tile_shard", None), getattr(pipe, "tile_all_reduce", None),
+             getattr(vae, "tile_shard", None), getattr(vae, "tile_all_reduce", None))
     enable_tile_sharding(pipe, sub, seed=None)
     outs = []
     try:
@@ -257,6 +262,9 @@ def run_hybrid(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise_fo
             outs.append(pipe.run(lq[i:i + 1], *run_args))
     finally:
         pipe.randn = prev
+        pipe.tile_shard, pipe.tile_all_reduce = saved[0], saved[1]
+        if vae is not None:
+            vae.tile_shard, vae.tile_all_reduce = saved[2], saved[3]
     out = np.concatenate(outs, axis=0) if outs else np.zeros((0,) + tuple(lq.shape[1:]), dtype=np.uint8)
     if not gather:
         return out

@@ -86,6 +86,11 @@ class SpacedSampler(Sampler):
         use_cfg = not (uncond is None or cfg_scale == 1.0)
         if use_cfg:
             cond2 = self._cfg_batch(cond, uncond, bs)
+        # the per-step host timestep (an engine extension read by ControlLDM.forward) goes into PRIVATE copies: the caller's
+        # dict is never written, so a cond reused by another sampler / a direct model call cannot carry a stale timestep
+        cond = dict(cond)
+        if use_cfg:
+            cond2 = dict(cond2)
         total = len(self.timesteps)
         it = np.flip(self.timesteps)
         if progress:

@@ -227,6 +227,10 @@ def supported(C: int, L: int, Lk: int, M: Optional[int] = None) -> bool:
         return False
     if C == 640 and M is not None and M // bm < MIN_PANELS_640:
         return False
+    # the C side addresses every tensor through a 2 GB buffer descriptor (the widest row is the [M, 2C] q | k output): a
+    # larger problem takes the per-operator path instead of failing in dbir_xf_head / dbir_xf_tail
+    if M is not None and (M * 2 * C) * 2 >= 0x7FFFFE00:
+        return False
     return True
 
 

@@ -110,8 +110,13 @@ typedef struct dbir_gemm_desc {
                90 - 92: producer / consumer split — four extra loader waves issue every direct-to-LDS copy, the matrix
                waves only read fragments and issue MFMAs (3-slot ring, one barrier per K tile, no split-K): 128x160 (4 matrix
                waves), 128x128 (4), 256x128 (8).
-               Ids 60 - 67 exist only in a DBIR_DIAG build (diagnostic ablations, meaningless outputs); 13 and 74 - 89
-               are invalid. */
+               80: fine-phase 256x320 kernel (gemm_8p.hip): 8 waves of 64x160, K stages of 32 through a 4-slot ring, two
+               wave groups one barrier apart (one multiplies while the other reads fragments / issues copies), counted
+               vmcnt; linear / 3x3 conv (stride 1 / 2, upsample) with K / Cin % 32 == 0, 16-bit row-major store, no
+               GEGLU; split-K is reduced INSIDE the launch (write-through f32 slabs + arrival ticket, last arriver sums in
+               slice order) and keeps the statistics stage; ws >= tiles * splitk * 327680 + tiles * 4 bytes.
+               Ids 60 - 67 exist only in a DBIR_DIAG build (diagnostic ablations, meaningless outputs); 13, 74 - 79 and
+               81 - 89 are invalid. */
   /* split-K (direct-to-LDS tiles >= 5 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
    * into f32 partial sums in `ws` (>= splitk * batch * M * N * 4 bytes, 16-byte aligned, caller-owned), then a second
    * kernel sums the slices in a fixed order and applies the epilogue.  For small-M / huge-K problems (8x8 and 16x16
@@ -121,10 +126,11 @@ typedef struct dbir_gemm_desc {
   long long ws_bytes;
   /* GroupNorm statistics of the OUTPUT straight from the epilogue (GroupNorm32 util.py:191-193 follows almost every
    * convolution of the UNet: unet.py:149-153,173-180, attention.py:48-51): stats != NULL asks the launched kernel for the
-   * per (row tile, column) sums of the STORED 16-bit values and of their squares, stats[tile_m][2][N] f32 (room for
-   * ceil(M / 64) * 2 * N floats).  IN/OUT: on return stats_rows = the rows per tile used (the launched kernel's tile
-   * height; M % stats_rows == 0), or 0 when this launch could not produce them (split-K, GEGLU, transposed / f32 store,
-   * batch > 1, the persistent / generic kernels, ragged M) — the caller then runs dbir_groupnorm_stats instead.
+   * per (row tile, column) statistics of the STORED 16-bit values, stats[tile_m][2][N] f32 (room for ceil(M / 64) * 2 * N
+   * floats): [0] = their sum, [1] = M2 = the sum of their squared deviations from that tile-column's own mean (shifted
+   * accumulation, pairwise merge: no cancellation when |mean| >> sigma).  IN/OUT: on return stats_rows = the rows per tile used (the launched kernel's tile
+   * height; M % stats_rows == 0), or 0 when this launch could not produce them (split-K except tile 80's in-launch reduce, GEGLU, transposed /
+   * f32 store, batch > 1, the persistent / generic kernels, ragged M) — the caller then runs dbir_groupnorm_stats instead.
    * dbir_groupnorm_from_partials turns the sums of one or two column-adjacent producers into mean / variance. */
   float* stats;
   int stats_rows;
@@ -180,7 +186,7 @@ int dbir_groupnorm_apply(int dtype, const void* x, long long ldx, void* y, long 
  * dbir_xf_head, which applies it while it loads its activation panel (same workspace contract as dbir_groupnorm). */
 int dbir_groupnorm_affine(int dtype, const void* x, long long ldx, int B, int HW, int C, int groups, float eps,
                           const float* gamma, const float* beta, float* workspace, float* scale_shift, void* stream);
-/* dbir_groupnorm_from_partials: GroupNorm statistics from the column sums that dbir_gemm epilogues emit (dbir_gemm_desc.stats):
+/* dbir_groupnorm_from_partials: GroupNorm statistics from the column (sum, M2) pairs that dbir_gemm epilogues emit (dbir_gemm_desc.stats):
  * the normalised tensor [B, HW, C] is the column concatenation of producer 1 (N1 columns) and producer 2 (N2 columns, or
  * NULL / 0): p[tile][2][N] with `rows` rows per tile (HW % rows == 0).  Writes mean_var f32 [B][mean(groups) | biased
  * var(groups)] (the layout dbir_groupnorm_apply takes) and / or scale_shift f32 [B][2][C] (dbir_xf_head); either may be NULL. */

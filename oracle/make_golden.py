@@ -233,6 +233,39 @@ def gen_full_bf16(R):
                         ref_cpu_seconds=np.float64(t_f32), ref_cpu_threads=np.int64(torch.get_num_threads()))
 
 
+# round 4: full-size fixtures for the paths that were pinned on the tiny config only
+FULL_SAMPLER_CASES = {   # name -> (sampler, steps): 1 x 512 x 512, CFG 4, seed 17 (as gen_samplers)
+    "ddim5": ("ddim", 5),
+    "edm_dpm++_2m_6": ("edm_dpm++_2m", 6),
+}
+
+
+@torch.no_grad()
+def gen_full_extra(R):
+    """tests/golden/full_extra.npz: (a) the reference's VAEHook at FULL network size — encode of a 1024 x 1024 image with
+    encoder tile 512, decode of a 128 x 128 latent with decoder tile 64 (what bench.py --vae-tiled switches on for every
+    N > 1 tiled run); (b) DDIM and edm_dpm++_2m pipelines at full size."""
+    from diffbir_amd import configs
+    cldm, swin, diff, W = build_reference(R, "full", configs.get("DIFFUSION_V21"))
+    g = {}
+    x = torch.tensor(cases.make_lq(51, 1, 1024, 1024)).float().div(255).permute(0, 3, 1, 2).contiguous()
+    t0 = time.time()
+    with cases.quiet():
+        g["enc_tiled_512"] = cldm.vae_encode(x * 2 - 1, sample=False, tiled=True, tile_size=512).numpy()
+        print("enc_tiled_512", g["enc_tiled_512"].shape, f"{time.time() - t0:.1f} s", flush=True)
+        z = cases.NoiseStream(52)((1, 4, 128, 128))
+        g["dec_tiled_64"] = cldm.vae_decode(z, tiled=True, tile_size=64).numpy().astype(np.float16)   # 12 MB as f32: stored f16
+        print("dec_tiled_64", g["dec_tiled_64"].shape, f"{time.time() - t0:.1f} s", flush=True)
+    pipe = R.SwinIRPipeline(swin, cldm, diff, None, "cpu")
+    for name, (sampler, steps) in FULL_SAMPLER_CASES.items():
+        torch.manual_seed(17)
+        with cases.quiet():
+            g[name] = pipe.run(cases.make_lq(53, 1, 512, 512), steps, 1.0, False, 512, 256, False, 256, False, 256, False,
+                               512, 256, "", cases.NEG_PROMPT, 4.0, "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
+        print(name, g[name].shape, f"{time.time() - t0:.1f} s", flush=True)
+    np.savez_compressed(os.path.join(OUT, "full_extra.npz"), **g)
+
+
 @torch.no_grad()
 def gen_tiled_vae(R):
     """Tiled VAE: the reference's VAEHook through ControlLDM.vae_encode / vae_decode with `tiled=True`
@@ -490,3 +523,5 @@ if __name__ == "__main__":
         gen_full_configs(R, only=sys.argv[2:] or None)
     elif what == "full_bf16":
         gen_full_bf16(R)
+    elif what == "full_extra":
+        gen_full_extra(R)

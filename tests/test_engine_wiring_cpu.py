@@ -262,3 +262,27 @@ def test_fused_control_injection_equals_two_pass_form(engine, monkeypatch):
     ctrl = cldm.controlnet(x, c_img, t, c_txt, scales=cldm.control_scales)
     feats = cldm.controlnet.features(x, c_img, t, c_txt)
     assert len(ctrl) == len(feats) == 13 and all(c.shape == f.shape for c, f in zip(ctrl, feats))
+
+
+def test_spaced_sampler_does_not_mutate_callers_cond(engine):
+    """the per-step host timestep (`t_host`, read by ControlLDM.forward for its time-embedding cache) must
+    live in the sampler's private copies — a cond dict reused after a spaced run would otherwise carry a stale timestep."""
+    from diffbir_amd.sampler import SpacedSampler
+    from diffbir_amd import configs
+    from diffbir_amd.model import Diffusion
+    diff = Diffusion(**configs.get("DIFFUSION_V21"))
+    seen = []
+
+    class _Model:
+        def forward(self, x, t, cond):
+            seen.append((float(t[0]), cond.get("t_host")))
+            return torch.zeros_like(x)
+
+    s = SpacedSampler(diff.betas, diff.parameterization, rescale_cfg=False)
+    s.randn = lambda shape: torch.zeros(shape)
+    cond = dict(c_txt=torch.zeros(1, 2, 4), c_img=torch.zeros(1, 4, 8, 8))
+    uncond = dict(c_txt=torch.ones(1, 2, 4), c_img=torch.zeros(1, 4, 8, 8))
+    keys_c, keys_u = set(cond), set(uncond)
+    s.sample(_Model(), "cpu", 3, (1, 4, 8, 8), cond, uncond, 4.0, progress=False)
+    assert set(cond) == keys_c and set(uncond) == keys_u, "sample() wrote into the caller's condition dicts"
+    assert len(seen) == 3 and all(th is not None and th == t for t, th in seen), seen

@@ -139,7 +139,10 @@ def _hybrid_worker(rank: int, world: int, port: int, outdir: str):
         local = parallel.run_hybrid(pipe, lq, ctx, args, noise_for_image=lambda i: cases.NoiseStream(5 + i), gather=False,
                                     split=split)
         np.save(os.path.join(outdir, f"hy_{rank}.npy"), local)
-        assert pipe.tile_shard == (rank % 2, 2)
+        # the pipeline's own sharding state is restored (nothing was set before the call): a later pipe.run must not
+        # all-reduce over this call's sub-group
+        assert getattr(pipe, "tile_shard", None) is None and getattr(pipe, "tile_all_reduce", None) is None
+        assert getattr(cldm.vae, "tile_shard", None) is None and getattr(cldm.vae, "tile_all_reduce", None) is None
         full = parallel.gather_group_outputs(local, 2, ctx, sub)
         if rank == 0:
             np.save(os.path.join(outdir, "hy_full.npy"), full)

@@ -19,13 +19,13 @@ import bench  # noqa: E402
 from diffbir_amd import native, ops, tuning  # noqa: E402
 
 CANDIDATES = [5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41, 44, 45, 50, 51, 52, 53, 70, 71, 72, 73,
-              90, 91, 92]   # tile ids (include/dbir.h)
+              80, 90, 91, 92]   # tile ids (include/dbir.h)
 SPLITK = [(10, 2), (10, 3), (10, 4), (10, 6), (10, 9), (12, 2), (12, 3), (12, 4), (5, 2), (5, 3), (14, 2), (14, 3), (14, 4),
           (15, 2), (15, 3), (30, 2), (30, 3), (30, 4), (30, 6), (30, 9), (32, 2), (32, 3), (25, 2), (25, 3), (34, 2), (34, 3),
           (34, 4), (35, 2), (35, 3), (36, 2), (36, 3), (37, 2), (37, 3), (37, 4), (40, 2), (40, 3), (40, 4), (40, 6),
           (40, 9), (50, 2), (50, 3), (50, 4), (50, 5), (50, 7), (50, 10), (51, 2), (51, 3), (51, 4), (51, 5), (51, 7),
           (51, 10), (52, 2), (52, 3), (52, 4), (52, 5), (52, 7), (52, 10), (53, 2), (53, 3), (53, 4), (53, 5), (53, 7),
-          (53, 10)]  # (tile, slices)
+          (53, 10), (80, 2), (80, 3), (80, 4), (80, 6), (80, 8)]  # (tile, slices)
 
 
 class Tuner:

@@ -37,6 +37,9 @@ LINS = [
     (65536, 320, 320, True, [0, 80]), (65536, 320, 1280, True, [0, 80]), (16384, 640, 640, True, [0, 80, 280]),
     (16384, 640, 2560, True, [0, 80, 280]), (4096, 1280, 1280, True, [0, 80, 280, 480]), (4096, 1280, 5120, True, [0, 280, 480]),
     (4096, 2560, 1280, False, [0, 80, 280]), (16384, 1280, 640, False, [0, 80]), (65536, 320, 640, False, [0, 80]),
+    # the feed-forward GEMMs of the 32x32 / 16x16 transformer blocks as PLAIN linears (same MFMA work as the GEGLU form)
+    (16384, 5120, 640, False, [0, 10, 30, 80]), (4096, 10240, 1280, False, [0, 10, 30, 80]),
+    (16384, 640, 2560, True, [0, 37, 50, 80, 280]), (65536, 2560, 320, False, [0, 10, 30, 80]),
 ]
 
 
