@@ -301,8 +301,9 @@ static int dbir_gemm_impl(const dbir_gemm_desc* dd, void* stream) {
   p.d = *dd;
   dbir_gemm_desc& d = p.d;
   // epilogue statistics: plain 16-bit row-major stores of the direct-to-LDS / halo kernels only
-  // (tile 80 reduces its K slices inside the launch and keeps the column-sum stage under split-K)
-  if (d.stats && (d.store_mode != 0 || d.out_f32 || d.act == DBIR_ACT_GEGLU || (d.splitk > 1 && d.tile != 80) || d.batch > 1 ||
+  // (split-K launches keep them since round 4: tile 80 reduces its K slices inside the launch, the other kernels' reduce
+  //  pass emits them per 64-row tile)
+  if (d.stats && (d.store_mode != 0 || d.out_f32 || d.act == DBIR_ACT_GEGLU || d.batch > 1 ||
                   (reinterpret_cast<uintptr_t>(d.stats) & 15)))
     d.stats = nullptr;
   DBIR_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "dbir_gemm: bad M/N/K %d %d %d", d.M, d.N, d.K);

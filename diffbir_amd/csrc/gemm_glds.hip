@@ -614,6 +614,88 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
   }
 }
 
+// The same second pass when the caller asked for GroupNorm statistics of the output (dbir_gemm_desc.stats; round 4: split-K
+// launches used to fall back to a separate statistics kernel over the stored tensor): a block owns a 64-row stripe x 256
+// columns, thread (row lane rl = tid / 32, chunk cl = tid % 32) walks 8 rows of its 8-column chunk, so the column statistics
+// of the STORED values (shifted sums, merged pairwise in a fixed order: gemm_epilogue.h ColStat) come out per 64-row tile:
+// stats[m / 64][2][N].  Needs M % 64 == 0 and one z slice.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const G2Params p) {
+  __shared__ __attribute__((aligned(16))) char sm[8 * 32 * 68];
+  const dbir_gemm_desc& d = p.d;
+  const int M = d.M, N = d.N;
+  const int tid = threadIdx.x, rl = tid >> 5, cl = tid & 31;
+  const int n0 = (blockIdx.y * 32 + cl) * 8;
+  const float* __restrict__ wsp = p.ws;
+  const u16* __restrict__ RV = reinterpret_cast<const u16*>(d.rowvec);
+  const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) : nullptr;
+  u16* __restrict__ Cg = reinterpret_cast<u16*>(d.C);
+  ColStat cs;
+  colstat_init(cs);
+  const bool active = n0 < N;
+  if (active) {
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = d.bias ? d.bias[n0 + e] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int m = blockIdx.x * 64 + rl + 8 * k;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      for (int sidx = 0; sidx < p.splitk; ++sidx) {
+        const float4* src = reinterpret_cast<const float4*>(wsp + ((long long)sidx * M + m) * N + n0);
+        const float4 a = src[0], b = src[1];
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+      if (RV) {
+        const u16* rvp = RV + (long long)(m / d.rows_per_batch) * d.rowvec_ld + n0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += T::to_f32(rvp[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e];
+        if (d.act == DBIR_ACT_SILU) x = silu_f(x);
+        else if (d.act == DBIR_ACT_GELU) x = gelu_fast(x);
+        else if (d.act == DBIR_ACT_LRELU) x = x > 0.f ? x : x * d.act_param;
+        v[e] = T::to_f32(T::from_f32(x * d.out_scale));   // same rounding points as the fused epilogue
+      }
+      if (Rg) {
+        const uint4 rr = *reinterpret_cast<const uint4*>(Rg + (long long)m * d.ldr + n0);
+        float b8[8];
+        unpack8<T>(rr, b8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+      }
+      const uint4 pk = pack8<T>(v);
+      *reinterpret_cast<uint4*>(Cg + (long long)m * d.ldc + n0) = pk;
+      unpack8<T>(pk, v);   // statistics of what was stored
+      colstat_add(cs, v);
+    }
+  }
+  colstat_finish<256, 256, 32, 8>(cs, active, sm, tid, cl, rl, d.stats + (long long)blockIdx.x * 2 * N, blockIdx.y, N);
+}
+
+// launch the split-K second pass (with or without the statistics stage) for the f32 slab layout [z][slice][M][N]
+template <typename T>
+int splitk_second_pass(const G2Params& p, hipStream_t s) {
+  const unsigned nz = p.d.batch > 0 ? p.d.batch : 1;
+  if (p.d.stats) {   // (callers only leave stats set when M % 64 == 0 and nz == 1)
+    hipLaunchKernelGGL((splitk_reduce_stats_kernel<T>), dim3((unsigned)(p.d.M / 64), (unsigned)cdiv(p.d.N >> 3, 32)), dim3(256),
+                       0, s, p);
+  } else {
+    const long long work = (long long)p.d.M * (p.d.N >> 3);
+    const unsigned rb = (unsigned)(work / 256 + 1 < 4096 ? work / 256 + 1 : 4096);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb, nz), dim3(256), 0, s, p);
+  }
+  DBIR_CHECK_LAUNCH("dbir_gemm(split-K reduce)");
+  return DBIR_OK;
+}
+
 template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, int DEPH = 0, int BKT = 64, int WPS = 0,
           int XPF = 0, int LDW = 0>
 int launch2(G2Params& p, hipStream_t s) {
@@ -658,8 +740,10 @@ int launch2(G2Params& p, hipStream_t s) {
   }
   p.mtiles = cdiv(p.d.M, BM);
   p.ntiles = cdiv(p.d.N, BN);
-  if (p.d.stats) {  // GroupNorm column sums of the output from the epilogue: whole tiles only
+  if (p.d.stats) {  // GroupNorm column statistics of the output: from the epilogue (whole tiles only), or — under split-K —
+                    // from the reduce pass in 64-row tiles
     if (p.splitk <= 1 && p.d.M % BM == 0) g_dbir_stats_rows = BM;
+    else if (p.splitk > 1 && p.d.M % 64 == 0 && p.d.batch <= 1) g_dbir_stats_rows = 64;
     else p.d.stats = nullptr;
   }
   const unsigned nz = p.d.batch > 0 ? p.d.batch : 1;
@@ -670,12 +754,7 @@ int launch2(G2Params& p, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + LDW)), lds, s, p);
   DBIR_CHECK_LAUNCH("dbir_gemm(glds)");
-  if (p.splitk > 1) {
-    const long long work = (long long)p.d.M * (p.d.N >> 3);
-    const unsigned rb = (unsigned)(work / 256 + 1 < 4096 ? work / 256 + 1 : 4096);
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb, nz), dim3(256), 0, s, p);
-    DBIR_CHECK_LAUNCH("dbir_gemm(split-K reduce)");
-  }
+  if (p.splitk > 1) return splitk_second_pass<T>(p, s);
   return DBIR_OK;
 }
 
@@ -733,15 +812,7 @@ int dbir_splitk_reduce_launch(const dbir_gemm_desc& d, int splitk, float* ws, hi
   p.d = d;
   p.splitk = splitk;
   p.ws = ws;
-  const long long work = (long long)d.M * (d.N >> 3);
-  const unsigned rb = (unsigned)(work / 256 + 1 < 4096 ? work / 256 + 1 : 4096);
-  const unsigned nz = d.batch > 0 ? d.batch : 1;
-  if (d.dtype == DBIR_F16)
-    hipLaunchKernelGGL((splitk_reduce_kernel<F16>), dim3(rb, nz), dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((splitk_reduce_kernel<BF16>), dim3(rb, nz), dim3(256), 0, s, p);
-  DBIR_CHECK_LAUNCH("dbir_gemm(split-K reduce)");
-  return DBIR_OK;
+  return d.dtype == DBIR_F16 ? splitk_second_pass<F16>(p, s) : splitk_second_pass<BF16>(p, s);
 }
 
 // Is the descriptor (already validated by dbir_gemm) runnable on the direct-to-LDS kernel?

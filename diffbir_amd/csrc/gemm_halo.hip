@@ -492,8 +492,9 @@ static int launch_halo(HParams& p, hipStream_t s) {
   }
   p.mtiles = cdiv(dd.M, BM);
   p.ntiles = cdiv(dd.N, BN);
-  if (p.d.stats) {  // GroupNorm column sums of the output from the epilogue: whole tiles only
+  if (p.d.stats) {  // GroupNorm column statistics: from the epilogue (whole tiles only) or, under split-K, from the reduce pass
     if (p.splitk <= 1 && dd.M % BM == 0 && !dd.out_f32) g_dbir_stats_rows = BM;
+    else if (p.splitk > 1 && dd.M % 64 == 0 && dd.batch <= 1 && !dd.out_f32) g_dbir_stats_rows = 64;
     else p.d.stats = nullptr;
   }
   auto kern = &gemm_halo_kernel<T, WM, WN, MI, NJ, PMAX, ABL, LS>;
@@ -506,7 +507,7 @@ static int launch_halo(HParams& p, hipStream_t s) {
   dim3 grid((unsigned)(p.mtiles * p.ntiles * p.splitk), nz);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
   DBIR_CHECK_LAUNCH("dbir_gemm(halo)");
-  if (p.splitk > 1) return dbir_splitk_reduce_launch(dd, p.splitk, p.ws, s);
+  if (p.splitk > 1) return dbir_splitk_reduce_launch(p.d, p.splitk, p.ws, s);
   return DBIR_OK;
 }
 

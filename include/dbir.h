@@ -129,8 +129,9 @@ typedef struct dbir_gemm_desc {
    * per (row tile, column) statistics of the STORED 16-bit values, stats[tile_m][2][N] f32 (room for ceil(M / 64) * 2 * N
    * floats): [0] = their sum, [1] = M2 = the sum of their squared deviations from that tile-column's own mean (shifted
    * accumulation, pairwise merge: no cancellation when |mean| >> sigma).  IN/OUT: on return stats_rows = the rows per tile used (the launched kernel's tile
-   * height; M % stats_rows == 0), or 0 when this launch could not produce them (split-K except tile 80's in-launch reduce, GEGLU, transposed /
-   * f32 store, batch > 1, the persistent / generic kernels, ragged M) — the caller then runs dbir_groupnorm_stats instead.
+   * height; M % stats_rows == 0), or 0 when this launch could not produce them (GEGLU, transposed / f32 store, batch > 1, the persistent /
+   * generic kernels, ragged M; split-K launches emit them from their reduce pass in 64-row tiles, tile 80 from its in-launch
+   * reduction) — the caller then runs dbir_groupnorm_stats instead.
    * dbir_groupnorm_from_partials turns the sums of one or two column-adjacent producers into mean / variance. */
   float* stats;
   int stats_rows;

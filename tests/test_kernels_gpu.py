@@ -328,7 +328,8 @@ def test_glds_deterministic():
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("code", [210, 310, 910, 212, 412, 305, 1005])
 def test_glds_splitk(code, dtype):
-    """split-K (tile + 100 * slices): f32 partial slabs + deterministic reduce kernel with the full epilogue."""
+    """split-K (tile + 100 * slices): f32 accumulator slabs reduced INSIDE the launch by the last-arriving slice (fixed slice
+    order: deterministic), which then runs the full epilogue."""
     # conv, deep K (9 taps x 256 ch = 36 K tiles), emb row vector + residual, N % 8 == 0 but ragged vs the tile
     x = rnd(2, 8, 8, 256, dtype=dtype)
     pw = ops.pack_conv3x3(rnd(200, 256, 3, 3, dtype=torch.float32, s=0.02, seed=1).cpu(),
@@ -437,7 +438,7 @@ def test_halo_conv3x3_fused_epilogue_and_splitk(tile, dtype):
     ops.conv3x3(x, pw, rowvec=emb, residual=res, out=oa[..., :N], tile=tile)
     emu.conv3x3(x, pw, rowvec=emb, residual=res, out=ob[..., :N])
     check(f"halo conv3x3 emb+res into concat view t{tile}", oa, ob, dtype, scale=1.5)
-    for sk in (2, 3, 4, 9):   # split-K over the 4 channel slices (clamped), deterministic reduce kernel
+    for sk in (2, 3, 4, 9):   # split-K over the 4 channel slices (clamped), reduced inside the launch
         code = tile + 100 * sk
         got = ops.conv3x3(x, pw, rowvec=emb, residual=res, act=emu.ACT_SILU, out_scale=0.7, tile=code)
         check(f"halo splitk code {code}", got,
@@ -636,13 +637,15 @@ def test_epilogue_group_norm_statistics(tile, dtype):
     assert torch.equal(ops.groupnorm(buf, gam, bet, 1e-5, True, stats=(st, None)), plain)
     assert torch.equal(ops.groupnorm(buf[..., :N1 + 64], gam[:N1 + 64], bet[:N1 + 64], 1e-5, True, stats=(st, st2), groups=32),
                        ops.groupnorm(buf[..., :N1 + 64], gam[:N1 + 64], bet[:N1 + 64], 1e-5, True, groups=32))
-    # launches that cannot emit them (ragged row tiles, split-K, f32 store) say so and the consumer falls back
+    # launches that cannot emit them (ragged row tiles, f32 store) say so and the consumer falls back
     xr = rnd(1, 30, 30, Cin, dtype=dtype, seed=11)
     outr, none1 = ops.conv3x3(xr, pc, stats=True)
     assert none1 is None and torch.equal(outr, ops.conv3x3(xr, pc))
-    if tile in (5, 12):
-        _, none2 = ops.conv3x3(x, pc, tile=tile + 200, stats=True)
-        assert none2 is None
+    if tile in (5, 12, 50, 52):
+        # split-K (round 4): the reduce pass emits them per 64-row tile
+        o3, st3 = ops.conv3x3(x, pc, residual=res, rowvec=emb, tile=tile + 200, stats=True)
+        assert st3 is not None and st3.rows == 64
+        _check_partials(f"conv t{tile} split-K 2", st3, o3, B * H * W)
 
 
 @pytest.mark.parametrize("tile", [0, 50, 52, 12, 80])
