@@ -36,7 +36,9 @@
 
 #include <type_traits>
 
-#define P8_VARIANTS 1  // TEMPORARY: diagnostic instantiations selected by env DBIR_P8_VAR
+#ifdef DBIR_DIAG  // `DBIR_DIAG=1 sh build.sh`: diagnostic instantiations of the kernel selected by env DBIR_P8_VAR
+#define P8_VARIANTS 1  // (tools/p8_diag.py: section stamps, ablations, schedule variants — never in the production library)
+#endif
 
 #include "common.h"
 #include "gemm_epilogue.h"

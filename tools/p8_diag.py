@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Anatomy of the fine-phase kernel (tile 80) on one convolution: per-section s_memtime accumulators (DBIR_P8_VAR=32/34)
+"""(needs a `DBIR_DIAG=1 sh diffbir_amd/csrc/build.sh` library)  Anatomy of the fine-phase kernel (tile 80) on one convolution: per-section s_memtime accumulators (DBIR_P8_VAR=32/34)
 and compile-time ablations (2 no setprio, 4 no MFMA, 8 no staging, 16 no fragment reads, 64 lgkmcnt before the barrier).
 Each variant needs its own process (the variant is read once): python tools/p8_diag.py <var> [B H W Cin Cout]"""
 import os
