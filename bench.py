@@ -77,7 +77,11 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pmc", action="store_true",
                     help="measure roofline.traffic in this job: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over "
-                         "the same network evaluation in subprocesses (+ ~2 min); default: the committed pass of this batch")
+                         "the same network evaluation in subprocesses (+ ~1 min).  Round 4: ON BY DEFAULT for the "
+                         "1-GPU run of the default configuration (the driver's BENCH line), see --no-pmc")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="never run the PMC passes: roofline.traffic then comes from the committed pass of this batch "
+                         "(profiles/r4_pmc_traffic_b<batch>.json) and traffic_source says so")
     ap.add_argument("--selftest", action="store_true",
                     help="CPU / gloo dry run of the launch, barrier, broadcast, gather, max-over-ranks and JSON plumbing "
                          "with a fake workload (tests/test_bench_plumbing_cpu.py); never a measurement")
@@ -192,7 +196,7 @@ def measure_roofline(cldm, device, batch, pmc=False):
         a[2] += 1
         a[3] += nbytes
     g = tot.get("gemm", [0.0, 1.0, 1, 0.0])
-    out = dict(bound="mfma", kernel="implicit-GEMM conv / linear family (gemm_halo / gemm_glds / gemm_pers / gemm kernels, split-K reduce, fused transformer kernels xf_head / xf_tail)",
+    out = dict(bound="mfma", kernel="implicit-GEMM conv / linear family (gemm_halo / gemm_8p / gemm_glds / gemm_pers / gemm kernels, split-K reduce, fused transformer kernels xf_head / xf_tail)",
                achieved=g[0] / g[1] / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=g[0] / g[1] / MFMA_PEAK,
                traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1], eval_batch=2 * batch,
                avg_launch_us=g[1] / g[2] * 1e6, flops_per_launch=g[0] / g[2],
@@ -214,18 +218,23 @@ def measure_roofline(cldm, device, batch, pmc=False):
                     out["traffic"] = tr["gemm_bytes_per_eval"] / g[2]
                     out["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two passes in this job "
                                              f"(tools/pmc_traffic.sh, evaluation batch {2 * batch})")
+                    keep = os.path.join(ROOT, "gpurun_out")   # scratch copy of the pass (profiles/ holds the committed one)
+                    if os.path.isdir(keep):
+                        shutil.copy(os.path.join(tmp, "pmc_traffic.json"), os.path.join(keep, f"pmc_traffic_b{batch}_injob.json"))
             except Exception as e:  # counters unavailable here: say so, never invent
                 out["traffic_source"] = f"PMC passes failed in this job ({type(e).__name__}); traffic not measured"
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
     if out["traffic"] is None:
-        pmc_file = os.path.join(ROOT, "profiles", f"r3_pmc_traffic_b{batch}.json")
+        pmc_file = os.path.join(ROOT, "profiles", f"r4_pmc_traffic_b{batch}.json")
+        if not os.path.exists(pmc_file):
+            pmc_file = os.path.join(ROOT, "profiles", f"r3_pmc_traffic_b{batch}.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 tr = json.load(f)
             if tr.get("gemm_bytes_per_eval"):
                 out["traffic"] = tr["gemm_bytes_per_eval"] / g[2]   # HBM bytes per logical GEMM launch
-                out["traffic_source"] = (f"profiles/r3_pmc_traffic_b{batch}.json (rocprofv3 --pmc passes of the same "
+                out["traffic_source"] = (f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc passes of the same "
                                          "evaluation, recorded on another box)")
     if "attention" in tot:
         a = tot["attention"]
@@ -485,7 +494,10 @@ def main():
     if args.selftest:
         res["data"] = "SELFTEST (fake workload, CPU/gloo) - not a measurement"
     if rank == 0 and not args.no_roofline and not args.selftest:
-        res["roofline"] = measure_roofline(cldm, device, 16 if cfg["tiled"] else args.batch, pmc=args.pmc)
+        # HBM traffic of the dominant kernel family is measured IN THIS JOB for the driver's line (1 GPU, default
+        # configuration) unless --no-pmc; other configurations measure it on request (--pmc)
+        want_pmc = (args.pmc or (world == 1 and args.config == "c2")) and not args.no_pmc
+        res["roofline"] = measure_roofline(cldm, device, 16 if cfg["tiled"] else args.batch, pmc=want_pmc)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.selftest:
