@@ -572,15 +572,29 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   const int rpb = RV ? d.rows_per_batch : 0x7fffffff;
   const int m_first = tm * BM, m_last = (tm * BM + BM - 1 < M ? tm * BM + BM - 1 : M - 1);
   const int samp0 = m_first / rpb, nsamp = m_last / rpb - samp0 + 1;
-  __syncthreads();  // operand ring dead
-  for (int q = tid; q < nsamp * BN; q += 512) {
+  auto tab_value = [&](int q) {
     const int sidx = q / BN, col = q - sidx * BN, n = tn * BN + col;
     float v = 0.f;
     if (n < N) {
       if (d.bias) v = d.bias[n];
       if (RV) v += T::to_f32(RV[(long long)(samp0 + sidx) * d.rowvec_ld + n]);
     }
-    tab[q] = v;
+    return v;
+  };
+  constexpr int TQ = 3;   // <= 4 samples per tile (the usual case): this thread's entries are requested in front of the barrier
+  float tv[TQ];
+  const bool tab_regs = nsamp * BN <= TQ * 512;
+  if (tab_regs) {
+#pragma unroll
+    for (int k = 0; k < TQ; ++k) tv[k] = tid + 512 * k < nsamp * BN ? tab_value(tid + 512 * k) : 0.f;
+  }
+  __syncthreads();  // operand ring dead
+  if (tab_regs) {
+#pragma unroll
+    for (int k = 0; k < TQ; ++k)
+      if (tid + 512 * k < nsamp * BN) tab[tid + 512 * k] = tv[k];
+  } else {
+    for (int q = tid; q < nsamp * BN; q += 512) tab[q] = tab_value(q);
   }
 
   // Pass h stages accumulator block i = h of EVERY wave: staged row lr = wm * 32 + lq <-> tile row wm * 64 + h * 32 + lq.

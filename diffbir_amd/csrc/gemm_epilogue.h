@@ -28,7 +28,6 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
-
 // ---- GroupNorm column statistics of the STORED tile (dbir_gemm_desc.stats) -------------------------------------------------
 // Per (row tile, column): stats[tile][0][n] = sum of the stored values, stats[tile][1][n] = M2 = sum of squared deviations
 // from that tile-column's own mean.  A thread accumulates its rows SHIFTED by its first value (no cancellation when
@@ -79,18 +78,23 @@ __device__ __forceinline__ void colstat_finish(const ColStat& c, bool active, ch
   for (int col = tid; col < BN; col += NT) {
     const int n = tn * BN + col;
     if (n >= N) continue;
-    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    // two passes over the row lanes, ONE division: mean = sum n_r mean_r / sum n_r, then M2 = sum [M2_r + n_r (mean_r - mean)^2]
+    // (the lanes' means are close to each other: no difference of large numbers; fixed order: deterministic)
+    float cnt = 0.f, sum = 0.f;
     for (int r = 0; r < RL; ++r) {
       const int slot = r * CPR + (col >> 3);
       const float nr = (float)pc[slot];
-      if (nr == 0.f) continue;
-      const float mr = ps[slot * 16 + (col & 7)], qr = ps[slot * 16 + 8 + (col & 7)];
-      const float tot = cnt + nr, dlt = mr - mean;
-      mean += dlt * (nr / tot);
-      m2 += qr + dlt * dlt * (cnt * nr / tot);
-      cnt = tot;
+      cnt += nr;
+      sum += nr * ps[slot * 16 + (col & 7)];
     }
-    st[n] = mean * cnt;
+    const float mean = cnt > 0.f ? sum / cnt : 0.f;
+    float m2 = 0.f;
+    for (int r = 0; r < RL; ++r) {
+      const int slot = r * CPR + (col >> 3);
+      const float nr = (float)pc[slot], dlt = ps[slot * 16 + (col & 7)] - mean;
+      m2 += ps[slot * 16 + 8 + (col & 7)] + nr * dlt * dlt;
+    }
+    st[n] = sum;
     st[N + n] = m2 > 0.f ? m2 : 0.f;
   }
 }
@@ -162,146 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const dbir_gemm_desc& d, const Epi
     }
     return;
   }
-  // ---------------- fast path (round 4): plain row-major 16-bit store (+ residual, + GroupNorm column sums) -------------
-  // What the epilogue used to wait for (profiles/r4_p8_diag_*.txt: 33 us of a 135 us launch) was not bandwidth but chains of
-  // dependent loads: per accumulator group one bias / row-vector load in front of its math, and per stored row one residual
-  // load in front of its store.  Here (a) bias[n] + rowvec[sample][n] of the <= 4 samples a tile touches are summed ONCE
-  // into an LDS table behind the staged tile (the register phase reads 16 B of LDS per group), and (b) all residual rows of
-  // a thread are requested through a tile-local buffer descriptor BEFORE the LDS round trip, so they arrive under it.
-  if (d.act != DBIR_ACT_GEGLU && d.store_mode == 0) {
-    constexpr int CS_LD = BN + 8, CPR = BN / 8, RL = NT / CPR, NRR = (BM + RL - 1) / RL;
-    constexpr int TAB_OFF = BM * CS_LD * 2, TABMAX = 4;
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-    u16* Cs = reinterpret_cast<u16*>(smem);
-    float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
-    const u16* __restrict__ RV = reinterpret_cast<const u16*>(d.rowvec);
-    const int rpb = RV ? d.rows_per_batch : 0x7fffffff;
-    const int m_first = tm * BM, m_last = (tm * BM + BM - 1 < M ? tm * BM + BM - 1 : M - 1);
-    const int samp0 = m_first / rpb, nsamp = m_last / rpb - samp0 + 1;
-    const bool use_tab = nsamp <= TABMAX;
-    const int ch = tid % CPR, rl = tid / CPR;
-    const int ncol = tn * BN + ch * 8;
-    const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) + (long long)bz * d.strideR_z : nullptr;
-    u16* __restrict__ Cg = reinterpret_cast<u16*>(d.C) + (long long)bz * d.strideC_z;
-    const bool streamer = rl < RL && ncol < N;
-    const bool full_chunk = ncol + 8 <= N;
-    const long long rows_left = (long long)M - (long long)tm * BM;
-    auto clip31 = [](long long b) { return (int)(b > 0x7ffffe00LL ? 0x7ffffe00LL : (b < 0 ? 0 : b)); };
-    const __amdgpu_buffer_rsrc_t c_srd = __builtin_amdgcn_make_buffer_rsrc(
-        Cg + (long long)tm * BM * d.ldc, 0, clip31(((rows_left - 1) * d.ldc + N) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_srd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<u16*>(Rg ? Rg + (long long)tm * BM * d.ldr : Cg), 0, Rg ? clip31(((rows_left - 1) * d.ldr + N) * 2) : 0,
-        0x00020000);
-    constexpr int OOBV = 0x7fffff00;
-    u32x4_t rres[NRR];
-    if (Rg && streamer && full_chunk) {
-#pragma unroll
-      for (int k = 0; k < NRR; ++k) {
-        const int row = rl + RL * k;
-        rres[k] = __builtin_amdgcn_raw_buffer_load_b128(r_srd, row < BM ? (row * (int)d.ldr + ncol) * 2 : OOBV, 0, 0);
-      }
-    }
-    __syncthreads();  // all waves finished reading the operand tiles (no glds in flight any more)
-    if (use_tab) {
-      for (int q = tid; q < nsamp * BN; q += NT) {
-        const int sidx = q / BN, col = q - sidx * BN, n = tn * BN + col;
-        float v = 0.f;
-        if (n < N) {
-          if (d.bias) v = d.bias[n];
-          if (RV) v += T::to_f32(RV[(long long)(samp0 + sidx) * d.rowvec_ld + n]);
-        }
-        tab[q] = v;
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int row = wm * 32 * MI + i * 32 + lq;
-      const int m = tm * BM + row;
-      const int mb = (m < M ? m : M - 1);
-      const u16* rvp = RV ? RV + (long long)(mb / d.rows_per_batch) * d.rowvec_ld : nullptr;
-      const float* trow = tab + (mb / rpb - samp0) * BN + wn * 32 * NJ + 4 * hi;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = wn * 32 * NJ + j * 32 + 8 * g + 4 * hi;
-          const int n0 = tn * BN + nl;
-          float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (use_tab) {
-            const float4 bb = *reinterpret_cast<const float4*>(trow + j * 32 + 8 * g);
-            v[0] += bb.x;
-            v[1] += bb.y;
-            v[2] += bb.z;
-            v[3] += bb.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n0 + e < N) v[e] += (d.bias ? d.bias[n0 + e] : 0.f) + (rvp ? T::to_f32(rvp[n0 + e]) : 0.f);
-          }
-          if (d.act == DBIR_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-          } else if (d.act == DBIR_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-          } else if (d.act == DBIR_ACT_LRELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * d.act_param;
-          }
-          uint2 pk;
-          pk.x = (uint32_t)T::from_f32(v[0] * d.out_scale) | ((uint32_t)T::from_f32(v[1] * d.out_scale) << 16);
-          pk.y = (uint32_t)T::from_f32(v[2] * d.out_scale) | ((uint32_t)T::from_f32(v[3] * d.out_scale) << 16);
-          *reinterpret_cast<uint2*>(Cs + row * CS_LD + nl) = pk;
-        }
-      }
-    }
-    __syncthreads();
-    ColStat cs;
-    colstat_init(cs);
-    const bool want_stats = d.stats != nullptr;
-    if (streamer) {
-#pragma unroll
-      for (int k = 0; k < NRR; ++k) {
-        const int row = rl + RL * k;
-        const int m = tm * BM + row;
-        if (row >= BM) continue;
-        float a[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(Cs + row * CS_LD + ch * 8), a);
-        if (full_chunk) {
-          if (Rg) {
-            float b[8];
-            unpack8<T>(__builtin_bit_cast(uint4, rres[k]), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += b[e];
-          }
-          const uint4 v = pack8<T>(a);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), c_srd, (row * (int)d.ldc + ncol) * 2, 0, 0);
-          if (want_stats && m < M) {
-            unpack8<T>(v, a);  // statistics of what was stored (16-bit rounded)
-            colstat_add(cs, a);
-          }
-        } else if (m < M) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = a[e];
-            if (ncol + e < N) {
-              if (Rg) x += T::to_f32(Rg[(long long)m * d.ldr + ncol + e]);
-              const u16 hv = T::from_f32(x);
-              Cg[(long long)m * d.ldc + ncol + e] = hv;
-              x = T::to_f32(hv);
-            }
-            a[e] = x;
-          }
-          if (want_stats) colstat_add(cs, a);
-        }
-      }
-    }
-    if (want_stats)
-      colstat_finish<NT, BN, CPR, RL>(cs, streamer, smem, tid, ch, rl, d.stats + (long long)tm * 2 * N, tn, N);
-    return;
-  }
-  // ---------------- GEGLU / transposed store: f32 math in registers -> 16-bit tile in LDS -> row-contiguous 16 B stores ----------
+  // ---------------- epilogue: f32 math in registers -> 16-bit tile in LDS -> row-contiguous 16 B stores ----------
   const bool geglu = d.act == DBIR_ACT_GEGLU;
   const int bn_out = geglu ? BN / 2 : BN;
   const int cs_ld = bn_out + 8;  // halfs; (bn_out + 8) * 2 B is a multiple of 16
@@ -415,7 +280,52 @@ __device__ __forceinline__ void gemm_epilogue(const dbir_gemm_desc& d, const Epi
     }
     return;
   }
-  {
+  if (d.stats) {
+    // ---- store + GroupNorm column sums of the STORED values (host side: no GEGLU, M % BM == 0, one z slice) --------------
+    // a thread keeps ONE 8-column chunk and walks the tile's rows with stride RL, so its 8 sums / 8 sums of squares stay
+    // in registers; the RL row lanes are then combined through LDS in a fixed order (deterministic) and every column of
+    // the tile gets its two numbers: stats[tm][0][n] = sum, stats[tm][1][n] = sum of squares over the tile's BM rows.
+    constexpr int CPR = BN / 8, RL = NT / CPR;
+    const int ch = tid % CPR, rl = tid / CPR;
+    const int ncol = tn * BN + ch * 8;
+    const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) : nullptr;
+    u16* __restrict__ Cg = reinterpret_cast<u16*>(d.C);
+    ColStat cs;
+    colstat_init(cs);
+    const bool active = rl < RL && ncol < N;
+    if (active) {
+      for (int row = rl; row < BM; row += RL) {
+        const int m = tm * BM + row;
+        float a[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(Cs + row * cs_ld + ch * 8), a);
+        if (ncol + 8 <= N) {
+          if (Rg) {
+            float b[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>(Rg + (long long)m * d.ldr + ncol), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += b[e];
+          }
+          const uint4 v = pack8<T>(a);
+          *reinterpret_cast<uint4*>(Cg + (long long)m * d.ldc + ncol) = v;
+          unpack8<T>(v, a);  // statistics of what was stored (16-bit rounded)
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (ncol + e < N) {
+              float x = a[e];
+              if (Rg) x += T::to_f32(Rg[(long long)m * d.ldr + ncol + e]);
+              const u16 hv = T::from_f32(x);
+              Cg[(long long)m * d.ldc + ncol + e] = hv;
+              a[e] = T::to_f32(hv);
+            }
+          }
+        }
+        colstat_add(cs, a);
+      }
+    }
+    // [sum, M2] per column of the tile: shifted per-thread sums merged pairwise through LDS in a fixed order (round 4)
+    colstat_finish<NT, BN, CPR, RL>(cs, active, smem, tid, ch, rl, d.stats + (long long)tm * 2 * N, tn, N);
+  } else {
     const int n_out = geglu ? N / 2 : N;
     const int ch_per_row = bn_out >> 3;
     const int total = BM * ch_per_row;

@@ -57,6 +57,7 @@ struct G2Params {
   int splitk, kt_per;    // split-K: number of K slices (1 = off) and K tiles per slice
   float* ws;             // split-K: f32 partial sums [z][slice][M][N]
   long long a_elems;     // elements of the activation tensor addressable from d.A (+ batch z offset)
+  int group_m;           // tile order: GROUP_M row tiles x all column tiles per group (1 = column tiles fastest)
   int tap_inner;         // conv K order: 1 = (channel tile, tap), 0 = (tap, channel tile)
   int debug;             // DIAGNOSTIC (env DBIR_GEMM_DEBUG): 1 = skip steady-state staging, 2 = skip MFMAs
 };
@@ -136,8 +137,22 @@ __global__ __launch_bounds__(64 * (WM * WN + LDW), MINW) void gemm_glds_kernel(c
     const int tiles = p.mtiles * p.ntiles;
     ksp = lid / tiles;  // K slice (0 when split-K is off)
     lid -= ksp * tiles;
-    tn = lid % p.ntiles;
-    tm = lid / p.ntiles;
+    // Tile order inside an XCD's contiguous range (round 4): the ~32 tiles an XCD runs AT THE SAME TIME stream K in step, so
+    // what its L2 must hold is one K window of every DISTINCT operand panel among them.  With column tiles fastest a
+    // wide problem (N / BN >= 8) runs 1 activation panel against 32 weight panels; groups of GROUP_M row tiles x all
+    // column tiles, row tile fastest, make the concurrent set GROUP_M x (32 / GROUP_M) (profiles/r4_pmc_traffic_b8.json:
+    // the 256x256 GEGLU tile fetched 335 MB per launch for 79 MB of operands).  Bijective for any tile counts.
+    if (p.group_m > 1) {
+      const int per = p.group_m * p.ntiles;
+      const int gid = lid / per, first = gid * p.group_m;
+      const int gsz = p.mtiles - first < p.group_m ? p.mtiles - first : p.group_m;
+      const int in = lid - gid * per;
+      tm = first + in % gsz;
+      tn = in / gsz;
+    } else {
+      tn = lid % p.ntiles;
+      tm = lid / p.ntiles;
+    }
   }
   const int M = d.M;
   const u16* __restrict__ Ag = reinterpret_cast<const u16*>(d.A) + (long long)bz * d.strideA_z;
@@ -615,17 +630,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G2Params p) {
 }
 
 // The same second pass when the caller asked for GroupNorm statistics of the output (dbir_gemm_desc.stats; round 4: split-K
-// launches used to fall back to a separate statistics kernel over the stored tensor): a block owns a 64-row stripe x 256
-// columns, thread (row lane rl = tid / 32, chunk cl = tid % 32) walks 8 rows of its 8-column chunk, so the column statistics
-// of the STORED values (shifted sums, merged pairwise in a fixed order: gemm_epilogue.h ColStat) come out per 64-row tile:
+// launches used to fall back to a separate statistics kernel over the stored tensor): a block owns a 64-row stripe x 64
+// columns (grid M / 64 x N / 64: the problems that need split-K are the small ones, they need the blocks), thread (row lane
+// rl = tid / 8, chunk cl = tid % 8) handles rows rl and rl + 32 of its 8-column chunk, so the column statistics of the
+// STORED values (shifted sums, merged pairwise in a fixed order: gemm_epilogue.h ColStat) come out per 64-row tile:
 // stats[m / 64][2][N].  Needs M % 64 == 0 and one z slice.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const G2Params p) {
-  __shared__ __attribute__((aligned(16))) char sm[8 * 32 * 68];
+  __shared__ __attribute__((aligned(16))) char sm[32 * 8 * 68];
   const dbir_gemm_desc& d = p.d;
   const int M = d.M, N = d.N;
-  const int tid = threadIdx.x, rl = tid >> 5, cl = tid & 31;
-  const int n0 = (blockIdx.y * 32 + cl) * 8;
+  const int tid = threadIdx.x, rl = tid >> 3, cl = tid & 7;
+  const int n0 = (blockIdx.y * 8 + cl) * 8;
   const float* __restrict__ wsp = p.ws;
   const u16* __restrict__ RV = reinterpret_cast<const u16*>(d.rowvec);
   const u16* __restrict__ Rg = d.R ? reinterpret_cast<const u16*>(d.R) : nullptr;
@@ -638,8 +654,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const G2Params
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = d.bias ? d.bias[n0 + e] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int m = blockIdx.x * 64 + rl + 8 * k;
+    for (int k = 0; k < 2; ++k) {
+      const int m = blockIdx.x * 64 + rl + 32 * k;
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -677,7 +693,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const G2Params
       colstat_add(cs, v);
     }
   }
-  colstat_finish<256, 256, 32, 8>(cs, active, sm, tid, cl, rl, d.stats + (long long)blockIdx.x * 2 * N, blockIdx.y, N);
+  colstat_finish<256, 64, 8, 32>(cs, active, sm, tid, cl, rl, d.stats + (long long)blockIdx.x * 2 * N, blockIdx.y, N);
 }
 
 // launch the split-K second pass (with or without the statistics stage) for the f32 slab layout [z][slice][M][N]
@@ -685,7 +701,7 @@ template <typename T>
 int splitk_second_pass(const G2Params& p, hipStream_t s) {
   const unsigned nz = p.d.batch > 0 ? p.d.batch : 1;
   if (p.d.stats) {   // (callers only leave stats set when M % 64 == 0 and nz == 1)
-    hipLaunchKernelGGL((splitk_reduce_stats_kernel<T>), dim3((unsigned)(p.d.M / 64), (unsigned)cdiv(p.d.N >> 3, 32)), dim3(256),
+    hipLaunchKernelGGL((splitk_reduce_stats_kernel<T>), dim3((unsigned)(p.d.M / 64), (unsigned)cdiv(p.d.N >> 3, 8)), dim3(256),
                        0, s, p);
   } else {
     const long long work = (long long)p.d.M * (p.d.N >> 3);
@@ -701,7 +717,7 @@ template <typename T, int WM, int WN, int MI, int NJ, int STAGES, int PIPE = 0, 
 int launch2(G2Params& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
   constexpr int RPP_ = 64 * (LDW ? LDW : WM * WN) / (BKT / 8), BNR = DEPH ? BN : (BN + RPP_ - 1) / RPP_ * RPP_;
-  constexpr int ring = STAGES * (BM + BNR) * BKT * 2, epi = BM * (BN + 8) * 2 + 16 * BN;  // operand ring / transposed C tile + (bias + row vector) table
+  constexpr int ring = STAGES * (BM + BNR) * BKT * 2, epi = BM * (BN + 8) * 2;  // operand ring / transposed C tile
   constexpr int lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   constexpr int blocks_per_cu = (160 * 1024) / lds;
@@ -740,6 +756,13 @@ int launch2(G2Params& p, hipStream_t s) {
   }
   p.mtiles = cdiv(p.d.M, BM);
   p.ntiles = cdiv(p.d.N, BN);
+  {
+    // OFF by default: measured per shape in the two-stream evaluation (profiles/r4_group_m_ab.txt) GROUP_M = 4 is neutral
+    // on the wide GEGLU tiles it was meant for and costs the 128x128 tile 2.4 us (6 %) on 4096 x 1280 x 1280; the L2-miss
+    // traffic it removes is not what those launches wait for.  DBIR_GROUP_M=4 switches it on for experiments.
+    static const int gm_env = getenv("DBIR_GROUP_M") ? atoi(getenv("DBIR_GROUP_M")) : 1;
+    p.group_m = (gm_env > 1 && p.ntiles >= 8 && p.mtiles >= gm_env) ? gm_env : 1;
+  }
   if (p.d.stats) {  // GroupNorm column statistics of the output: from the epilogue (whole tiles only), or — under split-K —
                     // from the reduce pass in 64-row tiles
     if (p.splitk <= 1 && p.d.M % BM == 0) g_dbir_stats_rows = BM;

@@ -45,6 +45,7 @@ struct HParams {
   int vec_bias, vec_rv;
   float* ws;
   int log2wo, log2rps;  // Wo and rows-per-segment are powers of two
+  int group_m;           // tile order: GROUP_M row tiles x all column tiles per group (1 = column tiles fastest)
   int nseg, P;          // segments per tile, patch pixels actually used (<= PMAX)
   long long a_elems;
 };
@@ -96,10 +97,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_halo_kernel(const HParam
     const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
     int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     const int tiles = p.mtiles * p.ntiles;
-    ksp = lid / tiles;
+    ksp = lid / tiles;  // K slice (0 when split-K is off)
     lid -= ksp * tiles;
-    tn = lid % p.ntiles;
-    tm = lid / p.ntiles;
+    // Tile order inside an XCD's contiguous range (round 4): the ~32 tiles an XCD runs AT THE SAME TIME stream K in step, so
+    // what its L2 must hold is one K window of every DISTINCT operand panel among them.  With column tiles fastest a
+    // wide problem (N / BN >= 8) runs 1 activation panel against 32 weight panels; groups of GROUP_M row tiles x all
+    // column tiles, row tile fastest, make the concurrent set GROUP_M x (32 / GROUP_M) (profiles/r4_pmc_traffic_b8.json:
+    // the 256x256 GEGLU tile fetched 335 MB per launch for 79 MB of operands).  Bijective for any tile counts.
+    if (p.group_m > 1) {
+      const int per = p.group_m * p.ntiles;
+      const int gid = lid / per, first = gid * p.group_m;
+      const int gsz = p.mtiles - first < p.group_m ? p.mtiles - first : p.group_m;
+      const int in = lid - gid * per;
+      tm = first + in % gsz;
+      tn = in / gsz;
+    } else {
+      tn = lid % p.ntiles;
+      tm = lid / p.ntiles;
+    }
   }
   const int Wo = d.Wo, Ho = d.Ho;
   const int rps = 1 << p.log2rps;
@@ -464,7 +479,7 @@ int dbir_splitk_reduce_launch(const dbir_gemm_desc& d, int splitk, float* ws, hi
 template <typename T, int WM, int WN, int MI, int NJ, int PMAX, int ABL = 0, int LS = 0>
 static int launch_halo(HParams& p, hipStream_t s) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-  constexpr int ring = 2 * (PMAX * 128 + 256) + 3 * BN * 128, epi = BM * (BN + 8) * 2 + 16 * BN;
+  constexpr int ring = 2 * (PMAX * 128 + 256) + 3 * BN * 128, epi = BM * (BN + 8) * 2;
   constexpr int lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   const dbir_gemm_desc& dd = p.d;
@@ -492,6 +507,13 @@ static int launch_halo(HParams& p, hipStream_t s) {
   }
   p.mtiles = cdiv(dd.M, BM);
   p.ntiles = cdiv(dd.N, BN);
+  {
+    // OFF by default: measured per shape in the two-stream evaluation (profiles/r4_group_m_ab.txt) GROUP_M = 4 is neutral
+    // on the wide GEGLU tiles it was meant for and costs the 128x128 tile 2.4 us (6 %) on 4096 x 1280 x 1280; the L2-miss
+    // traffic it removes is not what those launches wait for.  DBIR_GROUP_M=4 switches it on for experiments.
+    static const int gm_env = getenv("DBIR_GROUP_M") ? atoi(getenv("DBIR_GROUP_M")) : 1;
+    p.group_m = (gm_env > 1 && p.ntiles >= 8 && p.mtiles >= gm_env) ? gm_env : 1;
+  }
   if (p.d.stats) {  // GroupNorm column statistics: from the epilogue (whole tiles only) or, under split-K, from the reduce pass
     if (p.splitk <= 1 && dd.M % BM == 0 && !dd.out_f32) g_dbir_stats_rows = BM;
     else if (p.splitk > 1 && dd.M % 64 == 0 && dd.batch <= 1 && !dd.out_f32) g_dbir_stats_rows = 64;

@@ -36,7 +36,9 @@ extern "C" {
 
 const char* dbir_last_error(void);
 /* 3 since round 3: dbir_gemm takes a non-const descriptor (stats / stats_rows fields at its end), dbir_xf_head / dbir_xf_tail /
- * dbir_xf_geometry, dbir_groupnorm_affine, dbir_groupnorm_from_partials; tiles 80 - 89 retired, 90 - 92 added. */
+ * dbir_xf_geometry, dbir_groupnorm_affine, dbir_groupnorm_from_partials; tiles 80 - 89 retired, 90 - 92 added.
+ * 4 since round 4: dbir_gemm_desc.stats holds [sum, M2] per (row tile, column) instead of [sum, sum of squares] (and
+ * dbir_groupnorm_from_partials reads that), split-K launches emit them; tile 80 = the fine-phase 256x320 kernel. */
 int dbir_abi_version(void);
 /* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 2 (default) = LDS-resident
  * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape. */
