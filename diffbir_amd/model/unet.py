@@ -43,6 +43,12 @@ FUSED_XF_WIDTHS = {"0": (), "1": (320, 640), "320": (320,), "640": (640,)}.get(o
 # GroupNorm statistics from the producing GEMM's epilogue (column sums per output tile, ops.GnPartials) instead of a
 # statistics pass over the tensor (A/B switch: DBIR_GN_EPILOGUE_STATS=0)
 GN_EPI_STATS = os.environ.get("DBIR_GN_EPILOGUE_STATS", "1") != "0"
+# The 1x1 skip convolution of a decoder ResBlock (unet.py:203-223 `skip_connection`) depends only on the block's input: it CAN
+# be issued on the ControlNet's (by then idle) stream beside GroupNorm / conv1 / GroupNorm of the main path, which then waits
+# for its event right before conv2 adds it.  Measured in round 4 (profiles/r4_skip_side_ab.txt, same box, interleaved):
+# -0.4 ... -0.6 % at batch 8 and batch 4 — the main path's kernels are power- / bandwidth-limited, a kernel beside them takes
+# its time out of theirs.  OFF by default (DBIR_SKIP_SIDE=1 switches it on).
+SKIP_ON_SIDE = os.environ.get("DBIR_SKIP_SIDE", "0") == "1"
 
 
 def _unique_of_pairs(t: T, pair: Tuple[int, int]) -> T:
@@ -192,11 +198,26 @@ class _DiffusionNet(NativeModule):
         """-> (h, stats): `x_stats` / `stats` are the epilogue column sums (ops.GnPartials or None) of the block's input /
         output, from which the next GroupNorm takes its statistics without reading the tensor."""
         want = GN_EPI_STATS
+        skip, skip_ev = None, None
+        side = getattr(self, "_skip_side", None)
+        if r.skip is not None and side is not None and x.is_cuda:
+            main = torch.cuda.current_stream()
+            skip = torch.empty(x.shape[:-1] + (r.skip.n_out,), dtype=x.dtype, device=x.device)   # owned by the main stream
+            ready = torch.cuda.Event()
+            ready.record(main)                      # x (the concat buffer) is complete on this stream
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                ops.linear(x, r.skip, out=skip)
+                skip_ev = torch.cuda.Event()
+                skip_ev.record(side)
         h = ops.groupnorm(x, r.gn1[0], r.gn1[1], 1e-5, True, stats=x_stats)
         h, st = ops.conv3x3(h, r.conv1, rowvec=emb_all[:, r.emb_slice[0]:r.emb_slice[1]], stats=want) if want else \
             (ops.conv3x3(h, r.conv1, rowvec=emb_all[:, r.emb_slice[0]:r.emb_slice[1]]), None)
         h = ops.groupnorm(h, r.gn2[0], r.gn2[1], 1e-5, True, stats=st)
-        skip = x if r.skip is None else ops.linear(x, r.skip)
+        if skip_ev is not None:
+            torch.cuda.current_stream().wait_event(skip_ev)
+        elif skip is None:
+            skip = x if r.skip is None else ops.linear(x, r.skip)
         if want:
             return ops.conv3x3(h, r.conv2, residual=skip, out=out, stats=True)
         return ops.conv3x3(h, r.conv2, residual=skip, out=out), None
@@ -355,6 +376,7 @@ class ControlledUnetModel(_DiffusionNet):
         encoders are done, and run BESIDE the decoder blocks instead of between them (decoder block i waits for the event of
         its own injection only)."""
         self._ensure_packed()
+        self._skip_side = None
         ctx_kv = self.context_kv(context)
         emb_all = self._time_emb(timesteps, t_host)
         x = x.float().contiguous()
@@ -424,6 +446,8 @@ class ControlledUnetModel(_DiffusionNet):
         done, lst = add_control(h, left)     # lst / rst: column sums of the buffer's left / right part (GroupNorm statistics)
         if not done:
             left.copy_(h)
+        # (the side stream is idle from here on except for the injections issued above: the decoder's skip convolutions use it)
+        self._skip_side = control_stream if (pre is not None and SKIP_ON_SIDE) else None
         for i, (res, att, up, b) in enumerate(self.dec):
             skip = hs.pop()
             right = buf[..., b["cin"] - b["skip"]:]
@@ -448,6 +472,7 @@ class ControlledUnetModel(_DiffusionNet):
                 else:
                     h, lst = ops.conv3x3(h, up, upsample=True, out=target), None
             buf = nbuf
+        self._skip_side = None
         h = ops.groupnorm(h, self.out_gn[0], self.out_gn[1], 1e-5, True, stats=lst)
         o = ops.conv3x3(h, self.out_conv, out_f32=True)
         return ops.nhwc_to_nchw(o, self.plan.out_ch)
