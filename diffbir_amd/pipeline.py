@@ -54,7 +54,7 @@ class Pipeline:
         # engine extension (diffbir_amd.parallel): shard the tiles of tiled sampling over (rank, world)
         self.tile_shard: Optional[Tuple[int, int]] = None
         self.tile_all_reduce: Optional[Callable] = None
-        # engine extension: Brownian-motion factory handed to the EDM SDE solvers (sampler/edm_sampler.py BrownianPath)
+        # engine extension: Brownian-motion factory handed to the EDM SDE solvers (sampler/edm_sampler.py; None = the restated torchsde tree)
         self.brownian: Optional[Callable] = None
 
     def _randn(self, shape) -> torch.Tensor:

@@ -10,10 +10,12 @@ formulation), restated over three primitives:
   * `axpy`-style updates on the f32 latent (`dbir_lincomb4`);
   * a noise source.  Deterministic / ancestral solvers draw `randn_like(x)` from the device generator in exactly the
     reference's order (also the unused `eps` of the churn-free Euler / Heun / DPM-2 steps).  The SDE solvers need a
-    Brownian motion W over log-sigma time: the reference uses torchsde.BrownianTree (not installed in this environment,
-    not reproducible bit-wise); `BrownianPath` below is a native equivalent — a lazily refined Brownian bridge on the
-    device generator, consistent across overlapping intervals — so their noise REALISATION differs from torchsde's while
-    the process is the same.  `sampler.brownian` may be replaced (tests inject the same stand-in on both sides).
+    Brownian motion W over sigma time: the reference uses torchsde.BrownianTree through k-diffusion's
+    BrownianTreeNoiseSampler (k_diffusion.py:70-119); the engine's default is `brownian.BrownianTreeNoise`, a restatement
+    of that tree (seed drawn from torch's global CPU generator like the reference's, numpy SeedSequence keyed by tree
+    position, per-node torch generators) — unverified against a torchsde install, see sampler/brownian.py.
+    `sampler.brownian` may be replaced by a factory (x, randn, sigma_min, sigma_max) -> callable(sigma, sigma_next):
+    `BrownianPath` below (a lazily refined bridge on the sampler's own noise source) or a test stand-in.
 All scalar schedule math is done on the host in float32, mirroring the reference's f32 buffers.
 """
 import math
@@ -33,7 +35,7 @@ class BrownianPath:
     them, outside the known range from an independent increment.  Returns (W(t1) - W(t0)) / sqrt(|t1 - t0|), the
     convention of k-diffusion's BrownianTreeNoiseSampler (k_diffusion.py:97-119)."""
 
-    def __init__(self, x: torch.Tensor, randn: Callable):
+    def __init__(self, x: torch.Tensor, randn: Callable, *_sigma_range):
         self.shape, self.randn, self.like = tuple(x.shape), randn, x
         self.t: List[float] = []
         self.w: List[torch.Tensor] = []
@@ -94,8 +96,9 @@ class EDMSampler(Sampler):
             raise KeyError(name)
         self.solver = name
         self.hp = dict(s_churn=s_churn, s_tmin=s_tmin, s_tmax=s_tmax, s_noise=s_noise, eta=eta, order=order)
-        # engine extension: factory (x, randn) -> callable(sigma, sigma_next) for the SDE solvers
-        self.brownian: Callable = BrownianPath
+        # engine extension: factory (x, randn, sigma_min, sigma_max) -> callable(sigma, sigma_next) for the SDE solvers;
+        # None = the restated torchsde tree (brownian.BrownianTreeNoise, what the reference builds at k_diffusion.py:551,623,665)
+        self.brownian: Optional[Callable] = None
 
     # ---------------------------------------------------------------- schedule (reference edm_sampler.py:86-98)
     def make_schedule(self, steps: int) -> None:
@@ -306,8 +309,13 @@ class EDMSampler(Sampler):
             old = d0
         return x
 
-    def _brownian(self, x):
-        return self.brownian(x, self._randn_like(x))
+    def _brownian(self, x, sig):
+        """The noise sampler the reference builds as BrownianTreeNoiseSampler(x, sigmas[sigmas > 0].min(), sigmas.max())."""
+        smin, smax = float(min(s for s in sig if s > 0)), float(max(sig))
+        if self.brownian is not None:
+            return self.brownian(x, self._randn_like(x), smin, smax)
+        from .brownian import BrownianTreeNoise
+        return BrownianTreeNoise(x, smin, smax)
 
     def _randn_like(self, x):
         dev = x.device
@@ -315,7 +323,7 @@ class EDMSampler(Sampler):
 
     # ---- DPM-Solver++ SDE (k_diffusion.py:547-586); Brownian time = sigma itself (identity transform)
     def _solve_dpmpp_sde(self, den, x, sig, r: float = 0.5):
-        ns = self._brownian(x)
+        ns = self._brownian(x, sig)
         eta, s_noise = self.hp["eta"], self.hp["s_noise"]
         sf, tf = (lambda t: math.exp(-t)), (lambda s: -math.log(s) if s > 0 else math.inf)
         for i in range(len(sig) - 1):
@@ -329,18 +337,21 @@ class EDMSampler(Sampler):
             fac = 1 / (2 * r)
             sd, su = _ancestral(sf(t), sf(s), eta)
             s_ = tf(sd)
-            x2 = self._lin(x, sf(s_) / sf(t), d0, -math.expm1(t - s_), ns(sf(t), sf(s)), s_noise * su)
+            # the Brownian query times as the reference forms them: exp(-t) of float32 tensors (k_diffusion.py:555-556,576,583)
+            t32, tn32 = -_log(sig[i]), -_log(sig[i + 1])
+            q_t, q_s, q_n = (float(np.exp(-v)) for v in (t32, t32 + (tn32 - t32) * f32(r), tn32))
+            x2 = self._lin(x, sf(s_) / sf(t), d0, -math.expm1(t - s_), ns(q_t, q_s), s_noise * su)
             d2 = den(x2, sf(s))
             sd, su = _ancestral(sf(t), sf(t_next), eta)
             tn_ = tf(sd)
             k = -math.expm1(t - tn_)
             x = ops.lincomb4(x, self._full(sf(tn_) / sf(t)), d0, self._full(k * (1 - fac)), d2, self._full(k * fac),
-                             ns(sf(t), sf(t_next)), self._full(s_noise * su))
+                             ns(q_t, q_n), self._full(s_noise * su))
         return x
 
     # ---- DPM-Solver++(2M) SDE, midpoint (k_diffusion.py:615-657)
     def _solve_dpmpp_2m_sde(self, den, x, sig):
-        ns = self._brownian(x)
+        ns = self._brownian(x, sig)
         eta, s_noise = self.hp["eta"], self.hp["s_noise"]
         old, h_last = None, None
         for i in range(len(sig) - 1):
@@ -365,7 +376,7 @@ class EDMSampler(Sampler):
 
     # ---- DPM-Solver++(3M) SDE (k_diffusion.py:660-707)
     def _solve_dpmpp_3m_sde(self, den, x, sig):
-        ns = self._brownian(x)
+        ns = self._brownian(x, sig)
         eta, s_noise = self.hp["eta"], self.hp["s_noise"]
         d1_, d2_, h1, h2 = None, None, None, None
         for i in range(len(sig) - 1):

@@ -389,6 +389,38 @@ def gen_samplers(R):
     np.savez_compressed(os.path.join(OUT, "tiny_samplers.npz"), **g)
 
 
+# SDE solvers on the reference's OWN BrownianTreeNoiseSampler / BatchedBrownianTree (k_diffusion.py:70-119), running on the
+# restated torchsde tree of oracle/refshim/torchsde (parity of that tree with a real torchsde install is unpinned — its header
+# says so): what these fixtures pin is everything the reference does around the tree — the seed drawn from the global CPU
+# generator, sigma_min / sigma_max, the query times of each solver, sign and 1/sqrt|dt| normalisation — and that the engine's
+# independently written tree (diffbir_amd/sampler/brownian.py) realises the same noise.  name -> (sampler, steps, lq spec)
+SAMPLER_TREE_CASES = {
+    "edm_dpm++_sde": ("edm_dpm++_sde", 5, (3, 1, 512, 512)),
+    "edm_dpm++_2m_sde": ("edm_dpm++_2m_sde", 8, (3, 1, 512, 512)),
+    "edm_dpm++_3m_sde": ("edm_dpm++_3m_sde", 10, (3, 1, 512, 512)),
+    "edm_dpm++_3m_sde_b2": ("edm_dpm++_3m_sde", 6, (5, 2, 512, 512)),
+}
+
+
+@torch.no_grad()
+def gen_samplers_tree(R):
+    import importlib
+    from diffbir_amd import configs
+    kd = importlib.import_module("diffbir.sampler.k_diffusion")
+    assert kd.BrownianTreeNoiseSampler.__module__ == kd.__name__, "the reference's own noise sampler must be in place"
+    assert kd.torchsde.__version__.endswith("restated")
+    cldm, swin, diff, W = build_reference(R, "tiny", configs.get("DIFFUSION_V21"))
+    g = {}
+    for name, (sampler, steps, lq) in SAMPLER_TREE_CASES.items():
+        pipe = R.SwinIRPipeline(swin, cldm, diff, None, "cpu")
+        torch.manual_seed(17)
+        with cases.quiet():
+            g[name] = pipe.run(cases.make_lq(*lq), steps, 1.0, False, 512, 256, False, 256, False, 256, False, 512, 256, "",
+                               cases.NEG_PROMPT, 4.0, "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
+        print(name, g[name].shape, flush=True)
+    np.savez_compressed(os.path.join(OUT, "tiny_samplers_tree.npz"), **g)
+
+
 TINY_PIPE_CASES = {   # tiny end-to-end cases of tests/golden/tiny_pipeline.npz (v2.1 schedule)
     "spaced6_v21": ((3, 1, 512, 512), 6, "spaced", 231, {}),
     "dpm10_v21": ((3, 1, 512, 512), 10, "dpm++_m2", 231, {}),
@@ -513,6 +545,8 @@ if __name__ == "__main__":
         gen_tiled_vae(R)
     elif what == "samplers":
         gen_samplers(R)
+    elif what == "samplers_tree":
+        gen_samplers_tree(R)
     elif what == "ref_lowp":
         gen_ref_lowp(R)
     elif what == "tokenizer":

@@ -85,11 +85,37 @@ def run_sampler_case(pipe, name):
     a = dict(cfg=4.0, rescale_cfg=False, s_churn=0, s_tmin=0, s_tmax=300, s_noise=1, eta=1, order=1)
     a.update({k: v for k, v in kw.items() if k != "version"})
     pipe.randn = cases.NoiseStream(17)
-    pipe.brownian = lambda x, randn: (lambda sigma, sigma_next: randn(tuple(x.shape)))
+    pipe.brownian = lambda x, randn, *_range: (lambda sigma, sigma_next: randn(tuple(x.shape)))
     try:
         return pipe.run(cases.make_lq(3, 1, 512, 512), steps, 1.0, False, 512, 256, False, 256, False, 256, False, 512, 256,
                         "", cases.NEG_PROMPT, a["cfg"], "noise", sampler, 0, a["rescale_cfg"], a["s_churn"], a["s_tmin"],
                         a["s_tmax"], a["s_noise"], a["eta"], a["order"])
+    finally:
+        pipe.brownian = None
+
+
+# the SDE solvers on the restated torchsde tree (goldens: tests/golden/tiny_samplers_tree.npz, oracle/make_golden.py)
+SAMPLER_TREE_CASES = {
+    "edm_dpm++_sde": ("edm_dpm++_sde", 5, (3, 1, 512, 512)),
+    "edm_dpm++_2m_sde": ("edm_dpm++_2m_sde", 8, (3, 1, 512, 512)),
+    "edm_dpm++_3m_sde": ("edm_dpm++_3m_sde", 10, (3, 1, 512, 512)),
+    "edm_dpm++_3m_sde_b2": ("edm_dpm++_3m_sde", 6, (5, 2, 512, 512)),
+}
+
+
+def run_sampler_tree_case(pipe, name):
+    """Same call as oracle/make_golden.py gen_samplers_tree.  The engine's own Brownian tree (sampler/brownian.py), with the two
+    things the reference takes from torch's global CPU RNG state tied to the test's noise stream instead: the tree seed
+    (k_diffusion.py:78-79, drawn after x_T) and the per-node generators (the golden ran on device = cpu)."""
+    from diffbir_amd.sampler.brownian import BrownianTreeNoise
+    sampler, steps, lq = SAMPLER_TREE_CASES[name]
+    stream = cases.NoiseStream(17)
+    pipe.randn = stream
+    pipe.brownian = lambda x, randn, smin, smax: BrownianTreeNoise(
+        x, smin, smax, seed=int(torch.randint(0, 2 ** 63 - 1, [], generator=stream.g).item()), noise_device="cpu")
+    try:
+        return pipe.run(cases.make_lq(*lq), steps, 1.0, False, 512, 256, False, 256, False, 256, False, 512, 256, "",
+                        cases.NEG_PROMPT, 4.0, "noise", sampler, 0, False, 0, 0, 300, 1, 1, 1)
     finally:
         pipe.brownian = None
 

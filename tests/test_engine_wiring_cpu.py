@@ -10,8 +10,8 @@ import torch
 
 from oracle import cases
 from tests import emu_ops
-from tests.helpers import (OPTION_CASES, SAMPLER_CASES, build_cleaner, build_engine, rel_err, run_cleaner_pipeline,
-                           run_option_case, run_pipe, run_sampler_case)
+from tests.helpers import (OPTION_CASES, SAMPLER_CASES, SAMPLER_TREE_CASES, build_cleaner, build_engine, rel_err, run_cleaner_pipeline,
+                           run_option_case, run_pipe, run_sampler_case, run_sampler_tree_case)
 
 
 @pytest.fixture()
@@ -95,6 +95,20 @@ def test_ddim_edm_samplers_vs_reference_golden(monkeypatch, golden_dir, name):
     # cancels 1e4-sized terms down to ~10 and keeps ~4 digits there; the engine's fused a*x + b*D form keeps 7, so the two
     # differ at the 1e-4 level in the first latent (57-70 dB here) — an order below the fp16 network noise (52-55 dB)
     assert psnr > (55.0 if name.startswith("edm") else 60.0), psnr
+
+
+@pytest.mark.parametrize("name", sorted(SAMPLER_TREE_CASES))
+def test_sde_samplers_on_brownian_tree_vs_reference_golden(monkeypatch, golden_dir, name):
+    """The three SDE solvers with the engine's own Brownian tree (sampler/brownian.py) against the unmodified reference running
+    its BrownianTreeNoiseSampler / BatchedBrownianTree (k_diffusion.py:70-119) on the restated torchsde tree of
+    oracle/refshim/torchsde: seed draw, sigma range, per-solver query times, sign / normalisation and the tree itself."""
+    emu_ops.install(monkeypatch)
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", torch.device("cpu"), torch.float32, raw_dtype=True)
+    ref = np.load(os.path.join(golden_dir, "tiny_samplers_tree.npz"))[name]
+    out = run_sampler_tree_case(pipe, name)
+    assert out.shape == ref.shape and out.dtype == np.uint8
+    psnr = cases.psnr_u8(out, ref)
+    assert psnr > 55.0, psnr
 
 
 def test_tiled_vae_geometry_matches_reference(golden_dir):

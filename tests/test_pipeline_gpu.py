@@ -11,8 +11,8 @@ import pytest
 import torch
 
 from oracle import cases
-from tests.helpers import (OPTION_CASES, SAMPLER_CASES, build_engine, rel_err, run_option_case, run_pipe,
-                           run_sampler_case)
+from tests.helpers import (OPTION_CASES, SAMPLER_CASES, SAMPLER_TREE_CASES, build_engine, rel_err, run_option_case, run_pipe,
+                           run_sampler_case, run_sampler_tree_case)
 
 pytestmark = pytest.mark.gpu
 REPORT = {}
@@ -164,6 +164,45 @@ def test_ddim_edm_samplers_vs_reference_golden(golden_dir, name):
     REPORT[f"tiny_sampler_{name}_fp16"] = psnr
     print(name, f"PSNR {psnr:.2f} dB (bar {bar:.1f})")
     assert out.shape == ref.shape and psnr >= bar, (psnr, bar)
+
+
+@pytest.mark.parametrize("name", sorted(SAMPLER_TREE_CASES))
+def test_sde_samplers_on_brownian_tree_vs_reference_golden(golden_dir, name):
+    """The SDE solvers (incl. the reference CLI's default `edm_dpm++_3m_sde`, inference.py:91) with the engine's own Brownian
+    tree against the reference running its BrownianTreeNoiseSampler on the restated torchsde tree (oracle/make_golden.py
+    gen_samplers_tree; tests/test_brownian_cpu.py pins the tree itself).  fp16 bar as for the i.i.d.-noise cases."""
+    with open(os.path.join(golden_dir, "reference_lowp_psnr.json")) as f:
+        yard = json.load(f).get(f"sampler_{name}_fp16")
+    bar = 45.0 if yard is None else min(45.0, yard - 1.0)
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", _dev(), torch.float16)
+    ref = np.load(os.path.join(golden_dir, "tiny_samplers_tree.npz"))[name]
+    out = run_sampler_tree_case(pipe, name)
+    psnr = cases.psnr_u8(out, ref)
+    REPORT[f"tiny_sampler_tree_{name}_fp16"] = psnr
+    print(name, f"PSNR {psnr:.2f} dB (bar {bar:.1f})")
+    assert out.shape == ref.shape and psnr >= bar, (psnr, bar)
+
+
+def test_brownian_tree_default_path_draws_on_the_device_generator():
+    """Without a factory the SDE solvers build the tree like the reference (k_diffusion.py:551): seed from the global CPU
+    generator, node noise from generators on the latent's own device — reproducible per torch.manual_seed, unit variance."""
+    from diffbir_amd.sampler.brownian import BrownianTreeNoise
+    x = torch.zeros(2, 4, 64, 64, device=_dev())
+    torch.manual_seed(5)
+    a = BrownianTreeNoise(x, 0.0292, 1e4)
+    u = a(1e4, 312.5)
+    torch.manual_seed(5)
+    b = BrownianTreeNoise(x, 0.0292, 1e4)
+    assert u.device == x.device and torch.equal(u, b(1e4, 312.5))
+    assert abs(u.var().item() - 1.0) < 0.05 and abs(a(14.0, 3.0).var().item() - 1.0) < 0.05
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", _dev(), torch.float16)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        pipe.randn = cases.NoiseStream(17)
+        outs.append(pipe.run(cases.make_lq(3, 1, 512, 512), 4, 1.0, False, 512, 256, False, 256, False, 256, False, 512, 256,
+                             "", cases.NEG_PROMPT, 4.0, "noise", "edm_dpm++_3m_sde", 0, False, 0, 0, 300, 1, 1, 1))
+    assert cases.psnr_u8(outs[0], outs[1]) > 60.0   # same tree, same noise (the kernels' own run-to-run rounding aside)
 
 
 def test_full_pipeline_50_steps_vs_reference_golden(golden_dir):
