@@ -18,3 +18,4 @@ echo "rocprof rc=$? t=$(( $(date +%s) - T0 ))s"
 find gpurun_out/prof_f -name "*kernel_trace.csv" -delete
 sh tools/pmc_traffic.sh gpurun_out/pmc_f > gpurun_out/f_pmc.log 2>&1; echo "pmc rc=$? t=$(( $(date +%s) - T0 ))s"
 for c in c3 c4 c5; do timeout 600 python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/f_$c.log 2>&1; echo "$c rc=$? t=$(( $(date +%s) - T0 ))s"; tail -1 gpurun_out/f_$c.log | cut -c1-300; done
+bash tools/power_probe.sh gpurun_out/power_probe.txt > gpurun_out/f_power.log 2>&1; echo "power probe rc=$? t=$(( $(date +%s) - T0 ))s"

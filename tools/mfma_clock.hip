@@ -119,7 +119,56 @@ static void run(const char* what, int fill, int waves_per_simd, int iters) {
   free(h);
 }
 
-int main() {
+// `mfma_clock sustain <fill 0..3> <seconds>`: keep the f16 2-wave / SIMD loop running for <seconds> and report TF/s and the
+// effective clock of every half second (tools/power_probe.sh samples rocm-smi beside it)
+static void sustain(int fill, double seconds) {
+  unsigned short* h = (unsigned short*)malloc(4096 * 16);
+  for (int i = 0; i < 4096 * 8; ++i) {
+    float v = 0.f;
+    if (fill == 1) v = 0.5f;
+    if (fill == 2) v = 2.f * rand() / (float)RAND_MAX - 1.f;
+    if (fill == 3) v = nrand();
+    h[i] = f2h(v);
+  }
+  uint4* d;
+  unsigned long long* out;
+  float* sink;
+  hipMalloc(&d, 4096 * 16);
+  hipMalloc(&out, 256 * 16);
+  hipMalloc(&sink, 64);
+  hipMemcpy(d, h, 4096 * 16, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int iters = 4000, per = 200;                          // 200 launches of ~2.5 ms per report
+  double total = 0;
+  unsigned long long ho[512];
+  while (total < seconds) {
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < per; ++i) hipLaunchKernelGGL((k<0, 8>), dim3(256), dim3(512), 0, 0, d, iters, out, sink);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(ho, out, sizeof(ho), hipMemcpyDeviceToHost);
+    double st = 0, rt = 0;
+    for (int i = 0; i < 256; ++i) {
+      st += ho[2 * i];
+      rt += ho[2 * i + 1];
+    }
+    total += ms * 1e-3;
+    printf("sustain fill %d  t=%5.2f s  %6.0f TF/s  clock of the last launch %5.0f MHz\n", fill, total,
+           (double)per * iters * 16 * 32768.0 * 4 * 2 * 256 / (ms * 1e-3) * 1e-12, st / rt * 100.0);
+    fflush(stdout);
+  }
+  free(h);
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 4 && !strcmp(argv[1], "sustain")) {
+    sustain(atoi(argv[2]), atof(argv[3]));
+    return 0;
+  }
   const int iters = 4000;
   const char* names[4] = {"zeros", "const 0.5", "uniform[-1,1)", "normal(0,1)"};
   for (int fill = 0; fill < 4; ++fill) {
