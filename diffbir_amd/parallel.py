@@ -37,6 +37,7 @@ class DistContext:
     device: torch.device = torch.device("cpu")
     group: Optional[object] = None
     _noise: Optional[Callable] = None   # persistent shared-seed noise stream of run_data_parallel
+    _tree_seeds: Optional[torch.Generator] = None   # shared-seed source of the SDE solvers' Brownian-tree seeds
 
     @property
     def is_main(self) -> bool:
@@ -91,6 +92,21 @@ class ShardedNoise:
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         return lambda shape: torch.randn(tuple(shape), generator=g, dtype=torch.float32, device=device)
+
+
+class ShardedBrownianTree:
+    """The SDE solvers' Brownian tree (sampler/brownian.py) for a batch-sharded run: the tree is built for the FULL batch
+    from a seed every rank shares and each rank keeps its rows, so the restored images do not depend on the number of
+    GPUs (the per-node draws have the full-batch shape, as in a 1-GPU run of the whole batch)."""
+
+    def __init__(self, x_local: torch.Tensor, sigma_min: float, sigma_max: float, batch: int, lo: int, hi: int, seed: int,
+                 noise_device=None):
+        from .sampler.brownian import BrownianTreeNoise
+        full = torch.empty((batch,) + tuple(x_local.shape[1:]), dtype=torch.float32, device=x_local.device)
+        self.tree, self.lo, self.hi = BrownianTreeNoise(full, sigma_min, sigma_max, seed, noise_device=noise_device), lo, hi
+
+    def __call__(self, sigma: float, sigma_next: float) -> torch.Tensor:
+        return self.tree(sigma, sigma_next)[self.lo:self.hi].contiguous()
 
 
 def all_reduce_sum(ctx: DistContext) -> Callable:
@@ -288,15 +304,22 @@ def run_data_parallel(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, n
             ctx._noise = ShardedNoise.seeded(231, ctx.device)
         noise = ctx._noise
     base = noise
-    prev = pipe.randn
+    prev, prev_b = pipe.randn, pipe.brownian
     pipe.randn = ShardedNoise(base, B, lo, hi) if ctx.world > 1 else base
+    if prev_b is None:
+        # the SDE solvers' Brownian tree: one seed per call from a generator every rank seeds alike (drawn whether or not
+        # this call uses an SDE solver or this rank has rows, so the ranks stay in step), full-batch tree, this rank's rows
+        if ctx._tree_seeds is None:
+            ctx._tree_seeds = torch.Generator().manual_seed(231)
+        seed = int(torch.randint(0, 2 ** 63 - 1, [], generator=ctx._tree_seeds).item())
+        pipe.brownian = lambda x, randn, smin, smax: ShardedBrownianTree(x, smin, smax, B, lo, hi, seed)
     try:
         if hi > lo:
             out = pipe.run(lq[lo:hi], *run_args)
         else:  # more ranks than images
             out = np.zeros((0,) + tuple(lq.shape[1:]), dtype=np.uint8)
     finally:
-        pipe.randn = prev
+        pipe.randn, pipe.brownian = prev, prev_b
     if not gather:
         return out
     return gather_batch(out, B, ctx)
