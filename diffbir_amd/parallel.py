@@ -213,6 +213,17 @@ def enable_tile_sharding(pipe, ctx: DistContext, seed: Optional[int] = 231, chec
         pipe.tile_all_reduce = reduce
     if seed is not None and getattr(pipe, "randn", None) is None:
         pipe.randn = ShardedNoise.seeded(seed, ctx.device)
+    if seed is not None and getattr(pipe, "brownian", False) is None:
+        pipe.brownian = shared_seed_brownian(seed)   # the SDE solvers' tree seed must be the same on every rank too
+
+
+def shared_seed_brownian(seed: int) -> Callable:
+    """Brownian-tree factory (sampler/edm_sampler.py `brownian`) whose tree seeds come from a CPU generator seeded with
+    `seed` instead of the process's global one (k_diffusion.py:78-79 draws from the latter): identical on every rank."""
+    from .sampler.brownian import BrownianTreeNoise
+    g = torch.Generator().manual_seed(seed)
+    return lambda x, randn, smin, smax: BrownianTreeNoise(
+        x, smin, smax, seed=int(torch.randint(0, 2 ** 63 - 1, [], generator=g).item()))
 
 
 def hybrid_split(ctx: DistContext, n_images: int) -> Tuple[DistContext, int, int]:
@@ -264,7 +275,7 @@ def run_hybrid(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise_fo
     sub, lo, hi = split if split is not None else hybrid_split(ctx, B)
     if noise_for_image is None:
         noise_for_image = lambda i: ShardedNoise.seeded(231 + i, ctx.device)  # noqa: E731
-    prev = pipe.randn
+    prev, prev_b = pipe.randn, getattr(pipe, "brownian", None)
     # the sharding state the pipeline / its VAE had before this call comes back afterwards: a later
     # pipe.run or run_data_parallel on the same pipeline must not all-reduce over this call's sub-group
     vae = getattr(getattr(pipe, "cldm", None), "vae", None)
@@ -275,9 +286,11 @@ def run_hybrid(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, noise_fo
     try:
         for i in range(lo, hi):
             pipe.randn = noise_for_image(i)
+            if prev_b is None:
+                pipe.brownian = shared_seed_brownian(231 + i)   # per GLOBAL image, like its noise
             outs.append(pipe.run(lq[i:i + 1], *run_args))
     finally:
-        pipe.randn = prev
+        pipe.randn, pipe.brownian = prev, prev_b
         pipe.tile_shard, pipe.tile_all_reduce = saved[0], saved[1]
         if vae is not None:
             vae.tile_shard, vae.tile_all_reduce = saved[2], saved[3]
