@@ -38,6 +38,9 @@ sys.path.insert(0, ROOT)
 # SURVEY.md §8d algorithmic FLOPs (2*MAC; attention 4*Lq*Lk*d per head), per 512x512 image
 F_SWINIR, F_CLIP, F_VAE_ENC, F_VAE_DEC, F_EVAL = 0.181e12, 0.030e12, 1.117e12, 2.515e12, 1.073e12
 MFMA_PEAK = 2.5e15                # dense fp16/bf16, MI355X_MICROARCH.md
+# what a loop of nothing but v_mfma_f32_32x32x16_f16 sustains on normal(0, 1) operands under the 1400 W package limit
+# (tools/power_probe.sh, profiles/r4_power_probe.txt: 1332 W, 1.69 GHz) — context for `frac`, never the denominator of it
+MFMA_SUSTAINED_F16 = 1.62e15
 NEG = "low quality, blurry, low-resolution, noisy, unsharp, weird textures"
 
 CONFIGS = {
@@ -200,7 +203,10 @@ def measure_roofline(cldm, device, batch, pmc=False):
                achieved=g[0] / g[1] / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=g[0] / g[1] / MFMA_PEAK,
                traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1], eval_batch=2 * batch,
                avg_launch_us=g[1] / g[2] * 1e6, flops_per_launch=g[0] / g[2],
-               algorithmic_bytes_per_launch=g[3] / g[2])
+               algorithmic_bytes_per_launch=g[3] / g[2],
+               sustained_mfma_only_f16=dict(value=MFMA_SUSTAINED_F16 / 1e12, unit="TFLOP/s", frac_of_it=g[0] / g[1] / MFMA_SUSTAINED_F16,
+                                        source="profiles/r4_power_probe.txt: MFMA-only loop, normal(0,1) f16 operands, 1332 W of the "
+                                               "1400 W package limit at 1.69 GHz (2457 TFLOP/s at 937 W on zero operands)"))
     # HBM bytes per GEMM launch from rocprofv3 PMC passes (tools/pmc_traffic.sh; FETCH_SIZE doubled per the gfx950
     # correction in MI355X_MICROARCH.md, + WRITE_SIZE) on the same network evaluation: taken IN THIS JOB (two separate
     # --pmc passes in subprocesses, `pmc=True`), else from the last committed pass of the same evaluation batch
