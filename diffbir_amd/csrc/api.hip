@@ -21,7 +21,7 @@ void dbir_xf_set_variant(int v);         // xformer.hip
 extern "C" int dbir_set_option(int key, int value) {
   switch (key) {
     case DBIR_OPT_ATTN_VARIANT:
-      DBIR_CHECK_ARG(value >= 2 && value <= 5, "dbir_set_option: attention variant must be 2 (default), 3 (generic kernel only), 4 / 5 (generic kernel at 4 / 3 waves per SIMD)");
+      DBIR_CHECK_ARG(value >= 2 && value <= 6, "dbir_set_option: attention variant must be 2 (default), 3 (generic kernel only), 4 / 5 / 6 (generic kernel with the pre-round-4 softmax at 4 / 3 / default waves per SIMD)");
       dbir_attention_set_variant(value);
       return DBIR_OK;
     case DBIR_OPT_XF_VARIANT:

@@ -18,6 +18,20 @@
 
 namespace {
 
+// acc + lo(pk) + hi(pk) of a packed 16-bit pair: one v_dot2_f32_f16 / v_dot2_f32_bf16 against (1, 1)
+template <typename T>
+__device__ __forceinline__ float dot2_ones(uint32_t pk, float acc);
+template <>
+__device__ __forceinline__ float dot2_ones<F16>(uint32_t pk, float acc) {
+  const f16x2 ones = {(f16)1.0f, (f16)1.0f};
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, pk), ones, acc, false);
+}
+template <>
+__device__ __forceinline__ float dot2_ones<BF16>(uint32_t pk, float acc) {
+  const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), ones, acc, false);
+}
+
 constexpr int KT = 64;        // keys per tile
 constexpr int K_LD = 64 + 8;  // K tile row (halfs): 144 B -> conflict-free ds_read_b128
 constexpr int V_LD = 64 + 4;  // V^T tile row (halfs): 136 B -> conflict-free ds_read_b64
@@ -34,7 +48,14 @@ constexpr int V_LD = 64 + 4;  // V^T tile row (halfs): 136 B -> conflict-free ds
 //     ragged last tile, and the O / l rescale is skipped while the running max grows by less than 2^8 for every
 //     row of the wave (guide T13; P is then bounded by 256, exact in f32 and well inside f16 / bf16 range; the
 //     decision precedes the tile's exponentials and its P.V, the textbook order).
-template <typename T, int OCC>
+//   * FOLD (round 4, the production form): per-score work cut from 4.3 to 2.8 VALU instructions.  (i) Q is multiplied by
+//     c = scale * log2(e) once per workgroup (f32 product, rounded once to the 16-bit operand) and the running maximum rides
+//     into the score MFMA as its C operand — a 16-register block holding -m_run, rewritten only on a rescale — so the
+//     accumulator comes out as s*c - m_run and p = exp2(acc): no v_fma per score.  (ii) the row sum is taken over the PACKED
+//     16-bit P with v_dot2_f32_f16 / _bf16 against a vector of ones (one instruction per two scores; it is also the sum of
+//     exactly the values the P.V MFMA multiplies).  The first tile sets m_run to its row maximum unconditionally; after
+//     that the 2^8 rule is unchanged.
+template <typename T, int OCC, bool FOLD = false>
 __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__ Q, long long q_bs, long long ldq,
                                                        const u16* __restrict__ K, long long k_bs, long long ldk,
                                                        const u16* __restrict__ Vt, long long vt_bs, long long ldvt,
@@ -70,15 +91,25 @@ __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       uint4 v = q_ok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
+      if (FOLD) {
+        float f[8];
+        unpack8<T>(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= c;
+        v = pack8<T>(f);
+      }
       qf[ks] = __builtin_bit_cast(typename T::vec8, v);
     }
   }
+  f32x16 negm;  // FOLD: -m_run in every element = the C operand of the first MFMA of each score block
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
   f32x16 o_acc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;  // m_run in the scaled log2 domain
+  float m_run = FOLD ? 0.f : -1e30f, l_run = 0.f;  // m_run in the scaled log2 domain
 
   const u16* Kg = K + (long long)b * k_bs + h * 64;
   const u16* Vg = Vt + (long long)b * vt_bs + (long long)(h * 64) * ldvt;
@@ -150,13 +181,16 @@ __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__
     f32x16 s_acc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (!FOLD) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         typename T::vec8 kf =
             *reinterpret_cast<const typename T::vec8*>(&Ks[(kb * 32 + lq) * K_LD + ks * 16 + hi * 8]);
-        s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
+        if (FOLD && ks == 0) s_acc[kb] = T::mfma32(kf, qf[0], negm);
+        else s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
       }
     }
     ATS(1);
@@ -175,29 +209,53 @@ __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mxs = mx * c;
-    if (!__all(mxs - m_run <= 8.0f)) {  // some row's max grew by more than 2^8: rescale everything once
-      const float m_new = fmaxf(m_run, mxs);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
-    }
     float psum = 0.f;
-    const float neg_m = -m_run;
+    if (FOLD) {
+      // the accumulators hold s*c - m_run.  First tile: m_run := the row maximum; later: the 2^8 rule of the header
+      if (kt == 0 || !__all(mx <= 8.0f)) {
+        const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+        m_run += delta;
+        if (kt != 0) {  // (o_acc = l_run = 0 in the first tile, and exp2(-delta) may overflow there)
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], c, neg_m));
-        s_acc[kb][r] = pv;
-        psum += pv;
+            for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_acc[kb][r] -= delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
       }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run += psum;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[kb][r] = __builtin_amdgcn_exp2f(s_acc[kb][r]);
+    } else {
+      const float mxs = mx * c;
+      if (!__all(mxs - m_run <= 8.0f)) {  // some row's max grew by more than 2^8: rescale everything once
+        const float m_new = fmaxf(m_run, mxs);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+      }
+      const float neg_m = -m_run;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], c, neg_m));
+          s_acc[kb][r] = pv;
+          psum += pv;
+        }
+    }
     ATS(2);
 
 #pragma unroll
@@ -206,6 +264,7 @@ __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[j] = s_acc[s >> 1][8 * (s & 1) + j];
       const uint4 pp = pack8<T>(pf);
+      if (FOLD) psum = dot2_ones<T>(pp.w, dot2_ones<T>(pp.z, dot2_ones<T>(pp.y, dot2_ones<T>(pp.x, psum))));
       const typename T::vec8 pfrag = __builtin_bit_cast(typename T::vec8, pp);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -216,6 +275,8 @@ __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__
         o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
       }
     }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run += psum;
     ATS(3);
     if (more) commit((kt + 1) & 1, kt + 1);  // the other buffer was last read in iteration kt-1 (barrier since)
     ATS(4);
@@ -399,7 +460,8 @@ int g_attn_variant = 2;
 }  // namespace
 
 // A/B switch (dbir_set_option): 2 = default (cross kernel for Lk <= 96, generic otherwise), 3 = generic kernel always,
-// 4 / 5 = default dispatch with the generic kernel compiled for 4 / 3 resident waves per SIMD
+// 4 / 5 / 6 = default dispatch with the generic kernel's pre-round-4 softmax (FOLD = false) compiled for 4 / 3 / default resident
+// waves per SIMD; 2 and 3 run the FOLD form (scale folded into Q, running maximum as the score MFMA's C operand, row sum by v_dot2)
 void dbir_attention_set_variant(int v) { g_attn_variant = v; }
 
 extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, long long ldq, const void* K,
@@ -439,20 +501,23 @@ extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, lon
   }
   DBIR_CHECK_ARG((long long)cdiv(Lq, 128) * B * H < 2147483647LL, "dbir_attention: grid too large");
   const dim3 grid1((unsigned)(cdiv(Lq, 128) * B * H));
-#define ATTN2_LAUNCH(TT, OCC)                                                                                          \
-  hipLaunchKernelGGL((attn2_kernel<TT, OCC>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K,    \
-                     k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2)
-  // register budget variants (A/B through dbir_set_option): 2 waves / SIMD guaranteed (the compiler lands on 134 VGPRs =
-  // 3 resident), 4: capped at 128 VGPRs = 4 resident, 5: 3 resident by construction
+#define ATTN2_LAUNCH(TT, OCC, ...)                                                                                     \
+  hipLaunchKernelGGL((attn2_kernel<TT, OCC, ##__VA_ARGS__>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq,    \
+                     (const u16*)K, k_bstride, ldk, (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq,  \
+                     Lk, sl2)
+  // register budget variants (A/B through dbir_set_option): 2 waves / SIMD guaranteed (the compiler lands on 148 VGPRs for
+  // the FOLD form, 133 for the older one = 3 resident), 4: capped at 128 VGPRs = 4 resident, 5: 3 resident by construction
   const int occ = g_attn_variant == 4 ? 4 : (g_attn_variant == 5 ? 3 : 2);
   if (dtype == DBIR_F16) {
     if (occ == 4) ATTN2_LAUNCH(F16, 4);
     else if (occ == 3) ATTN2_LAUNCH(F16, 3);
-    else ATTN2_LAUNCH(F16, 2);
+    else if (g_attn_variant == 6) ATTN2_LAUNCH(F16, 2);
+    else ATTN2_LAUNCH(F16, 2, true);
   } else {
     if (occ == 4) ATTN2_LAUNCH(BF16, 4);
     else if (occ == 3) ATTN2_LAUNCH(BF16, 3);
-    else ATTN2_LAUNCH(BF16, 2);
+    else if (g_attn_variant == 6) ATTN2_LAUNCH(BF16, 2);
+    else ATTN2_LAUNCH(BF16, 2, true);
   }
 #undef ATTN2_LAUNCH
   DBIR_CHECK_LAUNCH("dbir_attention");

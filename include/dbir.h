@@ -41,7 +41,9 @@ const char* dbir_last_error(void);
  * dbir_groupnorm_from_partials reads that), split-K launches emit them; tile 80 = the fine-phase 256x320 kernel. */
 int dbir_abi_version(void);
 /* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 2 (default) = LDS-resident
- * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape. */
+ * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape, 4 / 5 =
+ * the generic kernel's pre-round-4 softmax compiled for 4 / 3 resident waves per SIMD, 6 = pre-round-4 softmax (scale and
+ * running maximum applied per score by a v_fma, f32 row sum) at the default register budget. */
 #define DBIR_OPT_ATTN_VARIANT 1
 /* DBIR_OPT_XF_VARIANT: weight staging schedule of dbir_xf_head / dbir_xf_tail — 1 (default) = the two wave groups stage
  * their shares of a tile at opposite ends of the tile's MFMAs, 0 = every wave stages first (A/B). */

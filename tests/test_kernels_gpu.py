@@ -998,7 +998,7 @@ ATT_CASES = [(2, 5, 1024, 1024), (1, 10, 256, 256), (2, 20, 64, 64), (2, 5, 1024
              (1, 1, 4096, 4096), (3, 4, 37, 200), (2, 20, 64, 77)]
 
 
-@pytest.fixture(params=[2, 3], ids=["attn_default", "attn_generic_only"])
+@pytest.fixture(params=[2, 3, 6], ids=["attn_default", "attn_generic_only", "attn_softmax_r3"])
 def attn_variant(request):
     """Default dispatch (LDS-resident cross kernel for Lk <= 96) and the generic flash kernel for every shape (include/dbir.h
     DBIR_OPT_ATTN_VARIANT); the default (2) is restored afterwards."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Self-attention kernel A/B (DBIR_OPT_ATTN_VARIANT): 2 = default, 4 / 5 =
-register-budget variants.  Interleaved, min of HIP-event timings.  python tools/attn_tile_ab.py [variants...]"""
+"""Self-attention kernel A/B (DBIR_OPT_ATTN_VARIANT): 2 = default (FOLD softmax), 6 = the pre-round-4 softmax, 4 / 5 =
+its register-budget variants.  Interleaved, min of HIP-event timings.  python tools/attn_tile_ab.py [variants...]"""
 import os
 import sys
 
