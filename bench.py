@@ -34,6 +34,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments written straight to device memory by the launching thread instead of being staged through a host-side
+# kernarg buffer: ~700 launches per network evaluation on two streams, +3.0 % on C2 (6.33 / 6.35 / 6.35 -> 6.53 / 6.53 / 6.52
+# img/s interleaved on one box, profiles/r4_kernarg_ab.txt).  Read by the HIP runtime when it initialises, so it is set before
+# anything imports torch; an explicit value in the environment wins.  (diffbir_amd/__init__.py sets the same default.)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 # SURVEY.md §8d algorithmic FLOPs (2*MAC; attention 4*Lq*Lk*d per head), per 512x512 image
 F_SWINIR, F_CLIP, F_VAE_ENC, F_VAE_DEC, F_EVAL = 0.181e12, 0.030e12, 1.117e12, 2.515e12, 1.073e12

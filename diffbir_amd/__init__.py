@@ -1,2 +1,10 @@
 """diffbir_amd — MI355X-native DiffBIR inference hot path (HIP kernels behind a C ABI)."""
 __version__ = "0.1.0"
+
+import os as _os
+
+# Launch-path default of the HIP runtime this engine was measured with (bench.py: +3.0 % on the C2 benchmark): kernel
+# arguments go straight to device memory.  The runtime reads it when it initialises (first HIP call of the process), so it
+# only takes effect when this package is imported before the first `torch.cuda` call; an explicit value in the environment
+# wins.  INTEGRATION.md, "Runtime environment".
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")

@@ -9,9 +9,12 @@ Checkpoints are looked up under ./weights/<file name of the reference's download
 and `--version v1 | v2 | v2.1 | custom` run on the engine (SwinIR / BSRNet / SCUNet stage-1 models); `unaligned_face`
 (RetinaFace detection) and the LLaVA / RAM captioners are outside it and raise with a pointer to DESIGN.md §7.
 """
+import os
 from argparse import ArgumentParser, Namespace
 
-import torch
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before torch initialises HIP (diffbir_amd/__init__.py says why)
+
+import torch  # noqa: E402
 
 DEFAULT_POS_PROMPT = (
     "Cinematic, High Contrast, highly detailed, taken using a Canon EOS R camera, "
