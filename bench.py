@@ -34,10 +34,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# kernel arguments written straight to device memory by the launching thread instead of being staged through a host-side
-# kernarg buffer: ~700 launches per network evaluation on two streams, +3.0 % on C2 (6.33 / 6.35 / 6.35 -> 6.53 / 6.53 / 6.52
-# img/s interleaved on one box, profiles/r4_kernarg_ab.txt).  Read by the HIP runtime when it initialises, so it is set before
-# anything imports torch; an explicit value in the environment wins.  (diffbir_amd/__init__.py sets the same default.)
+# kernel arguments in device memory (the runtime's own default on MI355X / ROCm 7.2, pinned here so that an inherited
+# HIP_FORCE_DEV_KERNARG=0 cannot silently cost 2.5 - 3 % of C2: ~700 launches per network evaluation on two streams,
+# profiles/r4_kernarg_ab.txt).  Read by the HIP runtime when it initialises, so it is set before anything imports torch; an
+# explicit value in the environment wins.  (diffbir_amd/__init__.py sets the same default.)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 # SURVEY.md §8d algorithmic FLOPs (2*MAC; attention 4*Lq*Lk*d per head), per 512x512 image

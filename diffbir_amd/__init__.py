@@ -3,8 +3,8 @@ __version__ = "0.1.0"
 
 import os as _os
 
-# Launch-path default of the HIP runtime this engine was measured with (bench.py: +3.0 % on the C2 benchmark): kernel
-# arguments go straight to device memory.  The runtime reads it when it initialises (first HIP call of the process), so it
-# only takes effect when this package is imported before the first `torch.cuda` call; an explicit value in the environment
-# wins.  INTEGRATION.md, "Runtime environment".
+# Launch path: kernel arguments in device memory.  It is the HIP runtime's own default on MI355X / ROCm 7.2; it is pinned
+# here because the engine issues ~700 launches per network evaluation and an inherited HIP_FORCE_DEV_KERNARG=0 costs 2.5 - 3 %
+# of the C2 benchmark (profiles/r4_kernarg_ab.txt).  The runtime reads the variable when it initialises (first HIP call of the
+# process); an explicit value in the environment wins.  INTEGRATION.md, "Runtime environment".
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
