@@ -34,10 +34,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# kernel arguments in device memory (the runtime's own default on MI355X / ROCm 7.2, pinned here so that an inherited
-# HIP_FORCE_DEV_KERNARG=0 cannot silently cost 2.5 - 3 % of C2: ~700 launches per network evaluation on two streams,
-# profiles/r4_kernarg_ab.txt).  Read by the HIP runtime when it initialises, so it is set before anything imports torch; an
-# explicit value in the environment wins.  (diffbir_amd/__init__.py sets the same default.)
+# kernel arguments in device memory: the runtime's own default on MI355X / ROCm 7.2.  Only a DEFAULT for an unset variable —
+# an inherited HIP_FORCE_DEV_KERNARG=0 (2.5 - 3 % slower on C2: ~700 launches per network evaluation on two streams,
+# profiles/r4_kernarg_ab.txt) is left in place and shows up in the JSON line as `launch_path.hip_force_dev_kernarg`.  Read by
+# the HIP runtime when it initialises, so it is set before anything imports torch.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 # SURVEY.md §8d algorithmic FLOPs (2*MAC; attention 4*Lq*Lk*d per head), per 512x512 image
@@ -90,6 +90,11 @@ def parse(argv=None):
     ap.add_argument("--no-pmc", action="store_true",
                     help="never run the PMC passes: roofline.traffic then comes from the committed pass of this batch "
                          "(profiles/r4_pmc_traffic_b<batch>.json) and traffic_source says so")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the multi-GPU code path on however many ranks there are — with ONE rank: RCCL communicator "
+                         "init, bucketed weight broadcast, one all-reduce per tiled evaluation, gather of the outputs on a "
+                         "one-rank communicator (tests/test_multigpu_gpu.py runs this on the 1-GPU box; results are "
+                         "bit-identical to the plain run).  Launch under torch.distributed.run --nproc-per-node 1")
     ap.add_argument("--selftest", action="store_true",
                     help="CPU / gloo dry run of the launch, barrier, broadcast, gather, max-over-ranks and JSON plumbing "
                          "with a fake workload (tests/test_bench_plumbing_cpu.py); never a measurement")
@@ -142,7 +147,7 @@ def build_engine(device, dtype, ctx=None):
     from diffbir_amd.parallel import broadcast_state_dict
     from diffbir_amd.pipeline import SwinIRPipeline
     g = torch.Generator(device=device).manual_seed(1234)
-    multi = ctx is not None and ctx.world > 1
+    multi = ctx is not None and ctx.multi
 
     def weights(mod):
         sd = rand_state_dict(mod._spec, device, g) if (not multi or ctx.rank == 0) else None
@@ -194,6 +199,11 @@ def measure_roofline(cldm, device, batch, pmc=False):
     cldm(x, t, cond)
     torch.cuda.synchronize()
     rec = ops.stop_profile()
+    from diffbir_amd import native
+    native.count_calls(True)          # host calls into the C ABI for ONE evaluation (launches per evaluation)
+    cldm(x, t, cond)
+    torch.cuda.synchronize()
+    c_abi_calls = native.count_calls(False)
     cldm.overlap_streams, cldm.use_graph = overlap, graph
     tot = {}
     for kind, flops, e0, e1, _tag, nbytes in rec:
@@ -208,7 +218,7 @@ def measure_roofline(cldm, device, batch, pmc=False):
                achieved=g[0] / g[1] / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=g[0] / g[1] / MFMA_PEAK,
                traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1], eval_batch=2 * batch,
                avg_launch_us=g[1] / g[2] * 1e6, flops_per_launch=g[0] / g[2],
-               algorithmic_bytes_per_launch=g[3] / g[2],
+               algorithmic_bytes_per_launch=g[3] / g[2], c_abi_calls_per_eval=c_abi_calls,
                sustained_mfma_only_f16=dict(value=MFMA_SUSTAINED_F16 / 1e12, unit="TFLOP/s", frac_of_it=g[0] / g[1] / MFMA_SUSTAINED_F16,
                                         source="profiles/r4_power_probe.txt: MFMA-only loop, normal(0,1) f16 operands, 1332 W of the "
                                                "1400 W package limit at 1.69 GHz (2457 TFLOP/s at 937 W on zero operands)"))
@@ -354,6 +364,8 @@ def main():
     cfg = CONFIGS[args.config]
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_spawn(args)
+    if args.force_collectives:
+        os.environ["DBIR_FORCE_COLLECTIVES"] = "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
@@ -364,12 +376,13 @@ def main():
     from diffbir_amd import parallel
     rank = int(os.environ.get("RANK", "0"))
     extra = {}
+    multi = world > 1 or args.force_collectives   # do the collectives run?  (== ctx.multi below)
     if args.selftest:
         ctx = parallel.init_distributed("gloo", torch.device("cpu"))
         device, sync = torch.device("cpu"), (lambda: None)
         dtype = torch.float16
         pipe = cldm = None
-        if world > 1:   # the weight broadcast with a small spec
+        if multi:   # the weight broadcast with a small spec
             spec = {"a.weight": ((64, 32), "w"), "a.bias": ((64,), "b"), "n.weight": ((7,), "g")}
             sd = rand_state_dict(spec, device, torch.Generator().manual_seed(5)) if rank == 0 else None
             got = parallel.broadcast_state_dict(sd, spec, ctx, bucket_bytes=4096)
@@ -392,13 +405,14 @@ def main():
         native.lib()
         dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
         pipe, cldm, swin = build_engine(device, dtype, ctx)
-        if world > 1:
+        if multi:
             extra["weights"] = "generated on rank 0, shipped by parallel.broadcast_state_dict (RCCL, 256 MB buckets)"
             try:   # informational only: never let it break a multi-GPU run
                 ver = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception as e:  # noqa: BLE001
                 ver = f"unknown ({type(e).__name__})"
-            extra["rccl"] = dict(ranks=dist.get_world_size(), backend=dist.get_backend(), version=ver)
+            extra["rccl"] = dict(ranks=dist.get_world_size(), backend=dist.get_backend(), version=ver,
+                                 forced_single_rank=bool(ctx.force and world == 1))
         rs = np.random.RandomState(100 + (0 if cfg["tiled"] else rank))
         lq = rs.randint(0, 256, (args.batch, cfg["size"], cfg["size"], 3)).astype(np.uint8)
         lq_dev = torch.as_tensor(lq).to(device)          # inputs resident in HBM before the timed region
@@ -435,15 +449,16 @@ def main():
                 full = parallel.run_data_parallel(pipe, lq_all, ctx, ra)
             if rank == 0:
                 np.save(args.parity_out, full)
+                extra.setdefault("rccl", {})["calls"] = dict(parallel.calls)
                 print(json.dumps(dict(parity_out=args.parity_out, shape=list(full.shape), n_gpus=world, **extra)), flush=True)
-            if world > 1:
+            if multi:
                 dist.barrier()
                 dist.destroy_process_group()
             return
 
     def barrier():
         sync()
-        if world > 1:
+        if multi:
             dist.barrier()
         sync()
 
@@ -455,18 +470,18 @@ def main():
         out = run_step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert out.dtype == np.uint8 and out.shape[0] == (args.batch if split is None else split[2] - split[1])
     sharded_batch = not cfg["tiled"]
-    if world > 1 and not sharded_batch and not args.selftest:   # group leaders' images -> rank 0 (outside the timed region)
+    if multi and not sharded_batch and not args.selftest:   # group leaders' images -> rank 0 (outside the timed region)
         full = parallel.gather_group_outputs(out, args.batch, ctx, split[0])
         if rank == 0:
             assert full.shape[0] == args.batch, full.shape
             extra["gathered_batch"] = list(full.shape)
-    if world > 1 and sharded_batch:   # outside the timed region: the restored slices travel to rank 0 over RCCL
+    if multi and sharded_batch:   # outside the timed region: the restored slices travel to rank 0 over RCCL
         full = parallel.gather_batch(out, args.batch * world, ctx)
         if rank == 0:
             assert full.shape == (args.batch * world,) + out.shape[1:], full.shape
@@ -499,6 +514,9 @@ def main():
                        "bf16 has 3 mantissa bits less = 18 dB); measured 41.2 dB against the reference's 40.4 dB on the "
                        "full-size tiled golden"),
     }
+    if multi and "rccl" in extra:
+        extra["rccl"]["calls"] = dict(parallel.calls)   # collectives issued by diffbir_amd.parallel in this process
+    res["launch_path"] = dict(hip_force_dev_kernarg=os.environ.get("HIP_FORCE_DEV_KERNARG"))
     res.update(extra)
     if not args.selftest:
         res["peak_mem_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
@@ -509,7 +527,7 @@ def main():
         # configuration) unless --no-pmc; other configurations measure it on request (--pmc)
         want_pmc = (args.pmc or (world == 1 and args.config == "c2")) and not args.no_pmc
         res["roofline"] = measure_roofline(cldm, device, 16 if cfg["tiled"] else args.batch, pmc=want_pmc)
-    if world > 1:
+    if multi:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.selftest:
         del pipe, cldm
@@ -517,7 +535,7 @@ def main():
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

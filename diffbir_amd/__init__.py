@@ -3,8 +3,12 @@ __version__ = "0.1.0"
 
 import os as _os
 
-# Launch path: kernel arguments in device memory.  It is the HIP runtime's own default on MI355X / ROCm 7.2; it is pinned
-# here because the engine issues ~700 launches per network evaluation and an inherited HIP_FORCE_DEV_KERNARG=0 costs 2.5 - 3 %
-# of the C2 benchmark (profiles/r4_kernarg_ab.txt).  The runtime reads the variable when it initialises (first HIP call of the
-# process); an explicit value in the environment wins.  INTEGRATION.md, "Runtime environment".
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Launch path: kernel arguments in device memory.  It is the HIP runtime's own default on MI355X / ROCm 7.2 (unset = 1), so
+# this only SUPPLIES A DEFAULT when the variable is unset; an inherited value — including an inherited 0, which costs 2.5 - 3 %
+# of the C2 benchmark (~700 launches per network evaluation, profiles/r4_kernarg_ab.txt) — is left alone, with a warning for
+# 0.  The runtime reads the variable when it initialises (first HIP call of the process): importing this package after HIP is
+# up changes nothing.  bench.py records the effective value in its JSON line.  INTEGRATION.md, "Runtime environment".
+if _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1") == "0":
+    import warnings as _warnings
+    _warnings.warn("diffbir_amd: HIP_FORCE_DEV_KERNARG=0 is set in the environment: kernel arguments are staged in host "
+                   "memory, which costs this engine 2.5 - 3 % (profiles/r4_kernarg_ab.txt); unset it or set it to 1")

@@ -13,7 +13,7 @@ void dbir_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dbir_last_error(void) { return g_err; }
-extern "C" int dbir_abi_version(void) { return 4; }
+extern "C" int dbir_abi_version(void) { return 5; }
 
 void dbir_attention_set_variant(int v);  // attention.hip
 void dbir_xf_set_variant(int v);         // xformer.hip

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__
   commit(0, 0);
   __syncthreads();
 
-#ifdef DBIR_DIAG  // tile-loop anatomy (tools/attn_diag.py): s_memtime accumulators per section
+#ifdef DBIR_DIAG  // tile-loop anatomy (tools/probes/attn_diag.py): s_memtime accumulators per section
   unsigned long long ta[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define ATS(I)                                                    \
   do {                                                            \
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__
   }
 #ifdef DBIR_DIAG
   // DIAG build only: the accumulators replace the first output row of this wave's 32-row slab — the harness
-  // (tools/attn_diag.py) reads them back from O and does not look at the attention result.  s_memtime does not order
+  // (tools/probes/attn_diag.py) reads them back from O and does not look at the attention result.  s_memtime does not order
   // vector instructions, so only the fetch / commit / barrier sections are reliable; MFMA + softmax issue is the rest.
   if (lane == 0) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(O + (long long)b * o_bs +

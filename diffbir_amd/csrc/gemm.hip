@@ -315,11 +315,17 @@ static int dbir_gemm_impl(const dbir_gemm_desc* dd, void* stream) {
                    d.K, d.lda);
     p.Hv = p.Wv = 0;
   } else if (d.mode == DBIR_MODE_CONV3X3) {
-    DBIR_CHECK_ARG(d.Cin % 8 == 0 && d.K == 9 * d.Cin, "dbir_gemm: conv needs Cin%%8==0 and K==9*Cin");
+    if (d.upsample == 2) {   // parity-collapsed nearest-x2 upsample convolution (gemm_8p.hip PH4): W = [4][Wrows][Kpad], K = 4 Cin
+      DBIR_CHECK_ARG(d.Cin % 32 == 0 && d.K == 4 * d.Cin, "dbir_gemm: upsample == 2 needs Cin%%32==0 and K==4*Cin");
+      DBIR_CHECK_ARG(d.tile % 100 == 80, "dbir_gemm: upsample == 2 runs on tile 80 only");
+    } else {
+      DBIR_CHECK_ARG(d.Cin % 8 == 0 && d.K == 9 * d.Cin, "dbir_gemm: conv needs Cin%%8==0 and K==9*Cin");
+      DBIR_CHECK_ARG(d.upsample == 0 || d.upsample == 1, "dbir_gemm: bad upsample %d", d.upsample);
+    }
     DBIR_CHECK_ARG(d.stride == 1 || d.stride == 2, "dbir_gemm: conv stride must be 1 or 2");
     DBIR_CHECK_ARG((long long)d.B * d.Ho * d.Wo == d.M, "dbir_gemm: conv M != B*Ho*Wo");
-    p.Hv = d.upsample ? 2 * d.Hi : d.Hi;
-    p.Wv = d.upsample ? 2 * d.Wi : d.Wi;
+    p.Hv = d.upsample == 1 ? 2 * d.Hi : d.Hi;
+    p.Wv = d.upsample == 1 ? 2 * d.Wi : d.Wi;
   } else {
     dbir_set_error("dbir_gemm: bad mode %d", d.mode);
     return DBIR_ERR_ARG;

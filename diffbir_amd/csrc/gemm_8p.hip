@@ -25,10 +25,21 @@
 //   * Operand fetch as in gemm_glds.hip: two block-local buffer descriptors, per-lane 32-bit offsets computed once, tap /
 //     channel-slice part in the scalar offset, hardware zero fill for padding; LDS image lane-linear with the bank swizzle
 //     (chunk ^ ((row >> 2) & 3)) on the SOURCE side and on the ds_read_b128 (guide rule 21): conflict-free.
-//   * Split-K INSIDE the launch (the 32x32 / 16x16 levels have only 128 / 64 tiles): the slices of a tile are adjacent block
-//     ids (same XCD); every slice writes its f32 accumulators, in register order, as write-through (sc1) 16-byte stores,
-//     drains them, and takes a ticket; the last arriver sums the slices in slice order (sc1 loads) and runs the epilogue
-//     (cdna_hip_programming.md §5 "In-launch split-K reduction").  No spin, no co-residency requirement, deterministic.
+//   * Split-K INSIDE the launch (the 32x32 / 16x16 levels have only 128 / 64 tiles): the slices of a tile are adjacent LOGICAL
+//     ids, which the bijective XCD remap keeps on one XCD only when (tiles * splitk) / 8 is a multiple of splitk — in general
+//     a tile's slices straddle two XCDs (e.g. splitk 3 / 9), and correctness never depends on the placement: every slice
+//     writes its f32 accumulators, in register order, as WRITE-THROUGH (sc1) 16-byte stores, every wave drains them
+//     (s_waitcnt vmcnt(0)) in front of the workgroup barrier, one lane takes an agent-scope ticket; the last arriver reads
+//     the slabs with sc1 loads (they bypass its L1, and an sc1-stored line is not kept in any XCD's L2, so the bytes come
+//     from memory) and sums them in slice order.  This is the drained-write-through hand-off of cdna_hip_programming.md §6
+//     Guideline 16 (R1) / MI355X_MICROARCH.md "Valid forms": "sc1 loads may replace the acquire only when the producer
+//     stored sc1" — no buffer_wbl2 / buffer_inv is needed, and a release fence here would only add an L2 write-back of
+//     unrelated dirty lines (1.7 - 6.5 us per workgroup).  No spin, no co-residency requirement, deterministic.
+//   * PH4 (round 5, desc.upsample == 2): nearest-x2 upsample + 3x3 convolution collapsed into FOUR 2x2 convolutions on the
+//     low-resolution input, one per output parity (a, b): output pixel (2i + a, 2j + b) reads the 2x2 low-resolution
+//     neighbourhood (i + a - 1 .., j + b - 1 ..) against the 3x3 taps that fall on each of those pixels SUMMED on the host
+//     (ops.pack_conv3x3_up4): 4 / 9 of the multiplies, exact algebra.  One launch runs all four phases (grid = 4 x the
+//     low-resolution tiles, phase-major), the epilogue scatters a tile's rows to their output pixels.
 //   * Epilogue: the math of gemm_epilogue.h (bias, time-embedding row vector, SiLU / GELU / LeakyReLU, scale, residual,
 //     GroupNorm column sums of the stored values) in two row passes of 128 rows (the 16-bit tile of 256 x 320 does not fit
 //     the LDS at once).
@@ -37,7 +48,7 @@
 #include <type_traits>
 
 #ifdef DBIR_DIAG  // `DBIR_DIAG=1 sh build.sh`: diagnostic instantiations of the kernel selected by env DBIR_P8_VAR
-#define P8_VARIANTS 1  // (tools/p8_diag.py: section stamps, ablations, schedule variants — never in the production library)
+#define P8_VARIANTS 1  // (tools/probes/p8_diag.py: section stamps, ablations, schedule variants — never in the production library)
 #endif
 
 #include "common.h"
@@ -58,6 +69,9 @@ struct P8 {
   float* ws;           // split-K: f32 accumulator slabs [tile][slice][40][512] float4
   unsigned* cnt;       // split-K: arrival counters [tile], zeroed ahead of the launch
   long long a_elems;
+  int ph_tiles;        // PH4: tiles per output parity (mtiles * ntiles); 0 otherwise
+  int st_tps;          // PH4: 256-row tiles per sample and parity (statistics rows are grouped per sample), 0 = no statistics
+  int lgW, lgHW;       // PH4: log2(Wi), log2(Hi * Wi)
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -84,6 +98,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   constexpr bool NOPRIO = (VAR & 2) != 0, NOMFMA = (VAR & 4) != 0, NOSTAGE = (VAR & 8) != 0, NOREAD = (VAR & 16) != 0;
   constexpr bool TIMING = (VAR & 32) != 0, LGK_EARLY = (VAR & 64) != 0;
   constexpr bool ONEBAR = (VAR & 128) != 0;       // one-barrier-per-phase schedule (see the ONEBAR block of the main loop)
+  constexpr bool PH4 = (VAR & 256) != 0;          // parity-collapsed nearest-x2 upsample convolution (2x2 taps, 4 phases)
+  static_assert(!(PH4 && UPS), "PH4 replaces the upsampled gather");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const unsigned long long rt_kernel = TIMING ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -95,17 +111,25 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   const int grp = wave >> 2;                      // wave group: 0 = waves 0-3 (also holds the third weight round)
 
   // ---- XCD-aware tile mapping (bijective); the K slices of a tile are consecutive logical ids -> same XCD ----
-  int tm, tn, ksp, tile;
+  int tm, tn, ksp, tile, phase = 0;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     tile = lid / p.splitk;
     ksp = lid - tile * p.splitk;
-    tn = tile % p.ntiles;
-    tm = tile / p.ntiles;
+    int t2 = tile;
+    if constexpr (PH4) {
+      phase = tile / p.ph_tiles;
+      t2 = tile - phase * p.ph_tiles;
+    }
+    tn = t2 % p.ntiles;
+    tm = t2 / p.ntiles;
   }
-  const int M = d.M;
+  const int pa = phase >> 1, pb = phase & 1;          // PH4: output row / column parity of this tile
+  const int M = PH4 ? d.B * d.Hi * d.Wi : d.M;        // rows of the tile space (PH4: low-resolution pixels)
+  const int rW = PH4 ? d.Wi : d.Wo, rHW = PH4 ? d.Hi * d.Wi : d.Ho * d.Wo;
+  const int py = PH4 ? 1 - pa : d.pad, px = PH4 ? 1 - pb : d.pad;   // tap (0, 0) sits at (oy * stride - py, ox * stride - px)
   const u16* __restrict__ Ag = reinterpret_cast<const u16*>(d.A);
   const u16* __restrict__ Wg = reinterpret_cast<const u16*>(d.W);
   const bool conv = d.mode == DBIR_MODE_CONV3X3;
@@ -120,11 +144,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   {
     const int m0 = tm * BM < M ? tm * BM : M - 1;
     if (conv) {
-      const int hw = d.Ho * d.Wo;
+      const int hw = rHW;
       const int b0 = m0 / hw, rem0 = m0 - b0 * hw;
-      const int oy0 = rem0 / d.Wo;
-      int sy0 = oy0 * d.stride - d.pad;
-      if (d.upsample) sy0 >>= 1;
+      const int oy0 = rem0 / rW;
+      int sy0 = oy0 * d.stride - py;
+      if (UPS) sy0 >>= 1;
       a_ref = ((long long)b0 * d.Hi * d.Wi + (long long)sy0 * d.Wi - 2) * d.Cin;
     } else {
       a_ref = (long long)m0 * d.lda;
@@ -135,8 +159,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   if (a_left < 0) a_left = 0;
   const __amdgpu_buffer_rsrc_t a_srd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(Ag) + a_ref, 0, (int)a_left, 0x00020000);
-  const long long w_ref = (long long)tn * BN * d.Kpad;
-  long long w_left = ((long long)d.Wrows * d.Kpad - w_ref) * 2;
+  const long long w_ref = ((long long)phase * d.Wrows + (long long)tn * BN) * d.Kpad;   // PH4: [parity][Wrows][Kpad]
+  long long w_left = ((long long)(phase + 1) * d.Wrows * d.Kpad - w_ref) * 2;
   if (w_left > 0x7ffffe00LL) w_left = 0x7ffffe00LL;
   if (w_left < 0) w_left = 0;
   const __amdgpu_buffer_rsrc_t w_srd =
@@ -149,20 +173,28 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
     const int m = tm * BM + srow + 128 * i;
     const bool ok = m < M;
     if (conv) {
-      const int hw = d.Ho * d.Wo;
+      const int hw = rHW;
       const int mm = ok ? m : 0;
       const int b = mm / hw;
       const int rem = mm - b * hw;
-      const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
-      const int iy0 = oy * d.stride - d.pad, ix0 = ox * d.stride - d.pad;
+      const int oy = rem / rW, ox = rem - oy * rW;
+      const int iy0 = oy * d.stride - py, ix0 = ox * d.stride - px;
       unsigned mk = 0;
+      if constexpr (PH4) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int iy = iy0 + t / 3, ix = ix0 + t % 3;
-        if (ok && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv) mk |= 1u << t;
+        for (int t = 0; t < 4; ++t) {
+          const int iy = iy0 + (t >> 1), ix = ix0 + (t & 1);
+          if (ok && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv) mk |= 1u << t;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+          if (ok && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv) mk |= 1u << t;
+        }
       }
       int sy = iy0, sx = ix0;
-      if (d.upsample) {
+      if (UPS) {
         mk |= (unsigned)(ix0 & 1) << 16 | (unsigned)(iy0 & 1) << 17;
         sy >>= 1;
         sx >>= 1;
@@ -193,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
 #define ISSUE_A(SLOT_)                                                                                   \
   do {                                                                                                   \
     char* ab_ = smem + (SLOT_) * SLOT + wave * 1024;                                                     \
-    const int ky_ = (a_tap * 11) >> 5, kx_ = a_tap - 3 * ky_;                                            \
+    const int ky_ = PH4 ? (a_tap >> 1) : ((a_tap * 11) >> 5), kx_ = PH4 ? (a_tap & 1) : a_tap - 3 * ky_; \
     const int koff_ = a_cc * ROWB;                                                                       \
     const unsigned tbit_ = 1u << a_tap;                                                                  \
     if constexpr (!UPS) {                                                                                \
@@ -557,8 +589,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
   // (loads return zero, stores are dropped)
   const long long rows_left = (long long)M - (long long)tm * BM;
   auto clip31 = [](long long b) { return (int)(b > 0x7ffffe00LL ? 0x7ffffe00LL : (b < 0 ? 0 : b)); };
+  // PH4: a tile's rows are low-resolution pixels scattered over the whole output -> one descriptor over the output tensor
+  // (dbir_gemm_8p_eligible bounds it below 2 GB), per-row offsets from orow_off()
   const __amdgpu_buffer_rsrc_t c_srd = __builtin_amdgcn_make_buffer_rsrc(
-      Cg + (long long)tm * BM * d.ldc, 0, clip31(((rows_left - 1) * d.ldc + N) * 2), 0x00020000);
+      PH4 ? Cg : Cg + (long long)tm * BM * d.ldc, 0,
+      clip31(((PH4 ? (long long)d.M - 1 : rows_left - 1) * d.ldc + N) * 2), 0x00020000);
+  // PH4: element offset (from Cg) of the output row that tile row `trow` (low-resolution pixel m = tm * BM + trow) produces
+  // for this tile's parity; Hi / Wi are powers of two (eligibility).  -1 for rows past the end.
+  auto orow_off = [&](int trow) -> long long {
+    const int m = tm * BM + trow;
+    if (m >= M) return -1;
+    const int j = m & (d.Wi - 1), i = (m >> p.lgW) & (d.Hi - 1), b = m >> p.lgHW;
+    return ((long long)(b * d.Ho + 2 * i + pa) * d.Wo + 2 * j + pb) * d.ldc;
+  };
   const __amdgpu_buffer_rsrc_t r_srd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<u16*>(Rg ? Rg + (long long)tm * BM * d.ldr : Cg), 0, Rg ? clip31(((rows_left - 1) * d.ldr + N) * 2) : 0,
       0x00020000);
@@ -652,6 +695,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
         if (lr >= 128) continue;
         float a[8];
         unpack8<T>(*reinterpret_cast<const uint4*>(Cs + lr * CS_LD + ch * 8), a);
+        long long oro = 0;   // PH4: output row offset (elements)
+        if constexpr (PH4) oro = orow_off(trow);
         if (full_chunk) {
           if (Rg) {
             float b[8];
@@ -660,19 +705,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
             for (int e = 0; e < 8; ++e) a[e] += b[e];
           }
           const uint4 v = pack8<T>(a);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_srd, (trow * (int)d.ldc + ncol) * 2, 0, 0);
+          const int so = PH4 ? (oro < 0 ? OOB : (int)((oro + ncol) * 2)) : (trow * (int)d.ldc + ncol) * 2;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_srd, so, 0, 0);
           if (want_stats && m < M) {
             unpack8<T>(v, a);  // statistics of what was stored (16-bit rounded)
             colstat_add(cstat, a);
           }
         } else if (m < M) {
+          const long long ro = PH4 ? oro : (long long)m * d.ldc;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float x = a[e];
             if (ncol + e < N) {
               if (Rg) x += T::to_f32(Rg[(long long)m * d.ldr + ncol + e]);
               const u16 hv = T::from_f32(x);
-              Cg[(long long)m * d.ldc + ncol + e] = hv;
+              Cg[ro + ncol + e] = hv;
               x = T::to_f32(hv);
             }
             a[e] = x;
@@ -695,8 +742,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const P8 p) {
     o[3] = rt_e1 - rt_e0;      // pass 0 (its stores issued)
     o[4] = rt_e2 - rt_e1;      // pass 1 + store drain
   }
-  if (want_stats)
-    colstat_finish<512, BN, CPR, RL>(cstat, streamer, smem, tid, ch, rl, d.stats + (long long)tm * 2 * N, tn, N);
+  if (want_stats) {
+    // PH4: the 4 * st_tps tiles of a sample (4 parities x st_tps low-resolution row tiles) are adjacent statistics rows
+    const long long srow = PH4 ? (long long)(tm / p.st_tps) * (4 * p.st_tps) + phase * p.st_tps + tm % p.st_tps : tm;
+    colstat_finish<512, BN, CPR, RL>(cstat, streamer, smem, tid, ch, rl, d.stats + srow * 2 * N, tn, N);
+  }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -714,12 +764,19 @@ bool dbir_gemm_8p_eligible(const dbir_gemm_desc& d) {
   } else {
     if (d.Cin % 32 != 0 || d.lda != d.Cin) return false;
     if ((long long)d.B * d.Hi * d.Wi >= 2147483647LL) return false;
+    if (d.upsample == 2) {   // PH4: four 2x2 convolutions on the low-resolution input, rows scattered to the output
+      auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+      if (d.R || d.rowvec || d.stride != 1 || d.pad != 1 || d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi) return false;
+      if (!pow2(d.Hi) || !pow2(d.Wi) || d.K != 4 * d.Cin) return false;
+      if (((long long)d.M - 1) * d.ldc + d.N >= (1LL << 30)) return false;           // 32-bit byte offsets into the output
+      if (4LL * d.Wrows * d.Kpad * 2 >= 0x7ffffe00LL) return false;
+    }
   }
   return true;
 }
 
 // bytes of workspace a split-K launch of this kernel needs (slabs + arrival counters)
-long long dbir_gemm_8p_ws_bytes(int M, int N, int splitk) {
+long long dbir_gemm_8p_ws_bytes(int M, int N, int splitk) {   // (PH4: pass M = 4 * ceil(B Hi Wi / 256) * 256)
   const long long tiles = (long long)cdiv(M, kBM) * cdiv(N, kBN);
   return tiles * splitk * (long long)kBM * kBN * 4 + tiles * 4 + 256;
 }
@@ -728,11 +785,20 @@ template <typename T, int VAR>
 static int launch_8p(P8& p, hipStream_t s) {
   constexpr int lds = 4 * (kBM + kBN) * 64;  // 147456: the ring; the epilogue's half tile (128 x 328 x 2 = 83968) reuses it
   const dbir_gemm_desc& dd = p.d;
-  p.ntaps = dd.mode == DBIR_MODE_LINEAR ? 1 : 9;
+  constexpr bool PH4 = (VAR & 256) != 0;
+  p.ntaps = dd.mode == DBIR_MODE_LINEAR ? 1 : (PH4 ? 4 : 9);
   p.nkc = (dd.mode == DBIR_MODE_LINEAR ? dd.K : dd.Cin) / 32;
-  p.mtiles = cdiv(dd.M, kBM);
+  p.mtiles = cdiv(PH4 ? dd.B * dd.Hi * dd.Wi : dd.M, kBM);
   p.ntiles = cdiv(dd.N, kBN);
-  const int tiles = p.mtiles * p.ntiles;
+  p.ph_tiles = PH4 ? p.mtiles * p.ntiles : 0;
+  p.st_tps = 1;
+  if (PH4) {
+    p.lgW = __builtin_ctz((unsigned)dd.Wi);
+    p.lgHW = p.lgW + __builtin_ctz((unsigned)dd.Hi);
+    p.Hv = dd.Hi;
+    p.Wv = dd.Wi;
+  }
+  const int tiles = p.mtiles * p.ntiles * (PH4 ? 4 : 1);
   const int nst_all = p.nkc * p.ntaps;
   int sk = dd.splitk > 1 ? dd.splitk : 1;
   if (sk > nst_all) sk = nst_all;
@@ -761,8 +827,18 @@ static int launch_8p(P8& p, hipStream_t s) {
   }
   if ((VAR & 32) && p.splitk <= 1) p.ws = reinterpret_cast<float*>(dd.ws);  // diagnostic timing dump
   if (p.d.stats) {
-    if (dd.M % kBM == 0) g_dbir_stats_rows = kBM;
-    else p.d.stats = nullptr;
+    if (PH4) {   // whole 256-row tiles per sample and parity
+      if ((dd.Hi * dd.Wi) % kBM == 0) {
+        p.st_tps = dd.Hi * dd.Wi / kBM;
+        g_dbir_stats_rows = kBM;
+      } else {
+        p.d.stats = nullptr;
+      }
+    } else if (dd.M % kBM == 0) {
+      g_dbir_stats_rows = kBM;
+    } else {
+      p.d.stats = nullptr;
+    }
   }
   auto kern = &gemm8p_kernel<T, VAR>;
   static bool attr_set = false;
@@ -789,6 +865,8 @@ int dbir_gemm_8p(const dbir_gemm_desc& dd, int Hv, int Wv, int tile, hipStream_t
     dbir_set_error("dbir_gemm: bad fine-phase tile %d", tile);
     return DBIR_ERR_ARG;
   }
+  if (dd.mode == DBIR_MODE_CONV3X3 && dd.upsample == 2)
+    return dd.dtype == DBIR_F16 ? launch_8p<F16, 256>(p, s) : launch_8p<BF16, 256>(p, s);
   if (dd.mode == DBIR_MODE_CONV3X3 && dd.upsample)
     return dd.dtype == DBIR_F16 ? launch_8p<F16, 1>(p, s) : launch_8p<BF16, 1>(p, s);
 #ifdef P8_VARIANTS

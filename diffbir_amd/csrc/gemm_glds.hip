@@ -92,7 +92,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // copy (and do nothing else) while the WM x WN matrix waves only read fragments and issue MFMAs.  A wave that issues the
 // copies stalls in VMEM issue while the copy engine drains (~34 B/clk per CU) and, issuing in order, cannot start its MFMAs
 // behind them; with the stall on separate waves the copy of K tile kt + 2 runs UNDER the MFMAs of tile kt instead of in
-// front of them (tools/lds_stream_bench.hip: 0.49 -> 0.37 us per 20 KB tile with 10 MFMAs per wave = the pure MFMA time).
+// front of them (tools/probes/lds_stream_bench.hip: 0.49 -> 0.37 us per 20 KB tile with 10 MFMAs per wave = the pure MFMA time).
 // One workgroup barrier per K tile: loaders wait for tile kt (counted vmcnt) in front of it and refill the slot of tile
 // kt - 1 behind it; matrix waves finish their fragment reads of tile kt - 1 (lgkmcnt(0)) in front of it.  Loaders leave
 // after the K loop (an ended wave no longer takes part in barriers), the matrix waves run the epilogue.
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LDW), MINW) void gemm_glds_kernel(c
 #undef ACQUIRE_X
   } else {
   // DIAGNOSTIC (kDiag build, debug == 5): per-wave s_memtime accumulators {vmcnt wait, barrier wait, first reads +
-  // stage issue, remaining reads + MFMA issue} -> workspace, read by tools/bench_one.py
+  // stage issue, remaining reads + MFMA issue} -> workspace, read by tools/probes/bench_one.py
   unsigned long long tacc0 = 0, tacc1 = 0, tacc2 = 0, tacc3 = 0, tprev = 0;
   const bool instr = kDiag && p.debug == 5;
 #define TSL(ACC)                                                   \

@@ -560,12 +560,12 @@ int dbir_gemm_halo(const dbir_gemm_desc& dd, int tile, hipStream_t s) {
     case 53:  // 256x128, lockstep schedule
       return f16 ? launch_halo<F16, 4, 2, 2, 2, 384, 0, 1>(p, s) : launch_halo<BF16, 4, 2, 2, 2, 384, 0, 1>(p, s);
 #ifdef DBIR_DIAG  // diagnostic ablations (f16 only, outputs are meaningless): only in a `DBIR_DIAG=1 sh build.sh` library,
-                  // never reachable through the production ABI (tools/halo_ablate.py)
+                  // never reachable through the production ABI (tools/probes/halo_ablate.py)
     case 64: return launch_halo<F16, 8, 1, 1, 5, 384, 1, 1>(p, s);   // ablations of tile 52
     case 65: return launch_halo<F16, 8, 1, 1, 5, 384, 2, 1>(p, s);
     case 66: return launch_halo<F16, 8, 1, 1, 5, 384, 3, 1>(p, s);
     case 67: return launch_halo<F16, 8, 1, 1, 5, 384, 4, 1>(p, s);
-    // diagnostic ablations of tile 50 (f16 only; outputs are meaningless): tools/halo_ablate.py
+    // diagnostic ablations of tile 50 (f16 only; outputs are meaningless): tools/probes/halo_ablate.py
     case 60: return launch_halo<F16, 8, 1, 1, 5, 384, 1>(p, s);
     case 61: return launch_halo<F16, 8, 1, 1, 5, 384, 2>(p, s);
     case 62: return launch_halo<F16, 8, 1, 1, 5, 384, 3>(p, s);

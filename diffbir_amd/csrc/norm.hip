@@ -458,6 +458,129 @@ __global__ __launch_bounds__(256) void gn_from_partials(const float* __restrict_
 }
 }  // namespace
 
+namespace {
+// gn_from_partials + gn_apply in ONE launch (round 5: 74 statistics-merge launches of ~5 us per network evaluation folded into
+// their consumers).  Every block first merges the per (row tile, column) [sum, M2] cells of ITS sample for all groups — the same
+// two-pass f64 merge as gn_from_partials (group mean, then M2 = sum_i [M2_i + n (mean_i - mean)^2]), TPG threads per group with
+// a fixed-order combine through LDS — then streams y = act(x * a + s) exactly like gn_apply.  The cells of a sample are
+// tiles * C f32 pairs (<= 40 KB, L2-resident: every block of the sample reads the same ones).
+template <typename T>
+__global__ void gn_apply_partials(const u16* __restrict__ x, long long ldx, u16* __restrict__ y, long long ldy,
+                                  const float* __restrict__ p1, int N1, const float* __restrict__ p2, int N2, int rows,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int groups,
+                                  float eps, int rows_per_blk, int rpi, int silu) {
+  __shared__ float stat[128];      // mean[groups], rstd[groups]
+  __shared__ double red[1024];
+  __shared__ double gmean[64];
+  const int CV = C >> 3;
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.y;
+  const int cpg = C / groups, tiles = HW / rows, cells = tiles * cpg;
+  const int TPG = nt / groups;                  // >= 2 (launcher)
+  const int g = t / TPG, j = t - g * TPG;
+  const bool act = g < groups;
+  const double n = (double)HW * cpg;
+  double s = 0.0;
+  if (act) {
+    for (int idx = j; idx < cells; idx += TPG) {
+      const int ti = idx / cpg, c = g * cpg + (idx - ti * cpg);
+      const long long tile = (long long)b * tiles + ti;
+      s += c < N1 ? p1[tile * 2 * N1 + c] : p2[tile * 2 * N2 + (c - N1)];
+    }
+  }
+  red[t] = s;
+  __syncthreads();
+  if (act && j == 0) {
+    double a = 0.0;
+    for (int k = 0; k < TPG; ++k) a += red[g * TPG + k];
+    gmean[g] = a / n;
+  }
+  __syncthreads();
+  double q = 0.0;
+  if (act) {
+    const double mean = gmean[g];
+    for (int idx = j; idx < cells; idx += TPG) {
+      const int ti = idx / cpg, c = g * cpg + (idx - ti * cpg);
+      const long long tile = (long long)b * tiles + ti;
+      const double si = c < N1 ? p1[tile * 2 * N1 + c] : p2[tile * 2 * N2 + (c - N1)];
+      const double qi = c < N1 ? p1[tile * 2 * N1 + N1 + c] : p2[tile * 2 * N2 + N2 + (c - N1)];
+      const double dm = si / rows - mean;
+      q += qi + dm * dm * rows;
+    }
+  }
+  red[t] = q;
+  __syncthreads();
+  if (act && j == 0) {
+    double a = 0.0;
+    for (int k = 0; k < TPG; ++k) a += red[g * TPG + k];
+    double var = a / n;
+    var = var > 0.0 ? var : 0.0;
+    stat[g] = (float)gmean[g];
+    stat[groups + g] = rsqrtf((float)var + eps);
+  }
+  __syncthreads();
+  const int cv = t % CV, rsub = t / CV;
+  float av[8], sv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cv * 8 + e;
+    const int gg = c / cpg;
+    const float a = stat[groups + gg] * gamma[c];
+    av[e] = a;
+    sv[e] = beta[c] - stat[gg] * a;
+  }
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(HW, r_begin + rows_per_blk);
+  const u16* xb = x + (long long)b * HW * ldx + cv * 8;
+  u16* yb = y + (long long)b * HW * ldy + cv * 8;
+  for (int r = r_begin + rsub; r < r_end; r += rpi) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xb + (long long)r * ldx);
+    float f[8];
+    unpack8<T>(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o = f[e] * av[e] + sv[e];
+      f[e] = silu ? silu_f(o) : o;
+    }
+    *reinterpret_cast<uint4*>(yb + (long long)r * ldy) = pack8<T>(f);
+  }
+}
+}  // namespace
+
+static int gn_geometry(int B, int HW, int C, int groups, int& nchunk, int& rows_per_chunk, int& rpi, int& threads);
+
+extern "C" int dbir_groupnorm_apply_partials(int dtype, const void* x, long long ldx, void* y, long long ldy,
+                                             const float* gamma, const float* beta, const float* p1, int N1, const float* p2,
+                                             int N2, int rows, int B, int HW, int groups, float eps, int silu, void* stream) {
+  const int C = N1 + N2;
+  DBIR_CHECK_ARG(x && y && gamma && beta && p1 && N1 > 0 && (N2 == 0 || p2) && N2 >= 0,
+                 "dbir_groupnorm_apply_partials: null pointer / bad producers");
+  DBIR_CHECK_ARG(rows > 0 && HW % rows == 0 && B > 0 && B <= 65535 && groups > 0 && groups <= 64 && C % groups == 0 &&
+                     C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 4096,
+                 "dbir_groupnorm_apply_partials: need HW %% rows == 0 (HW %d, rows %d), groups <= 64 dividing C, C %% 8 == 0", HW,
+                 rows);
+  int nchunk, rows_per_chunk, rpi, threads;
+  DBIR_CHECK_ARG(gn_geometry(B, HW, C, groups, nchunk, rows_per_chunk, rpi, threads),
+                 "dbir_groupnorm_apply_partials: unsupported C / groups combination");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int nblk = (512 + B - 1) / B;   // fewer, fatter blocks than gn_apply: each one repeats the merge of its sample's cells
+  int rows_per_blk = (HW + nblk - 1) / nblk;
+  if (rows_per_blk < rpi) rows_per_blk = rpi;
+  nblk = (HW + rows_per_blk - 1) / rows_per_blk;
+  if (dtype == DBIR_F16)
+    hipLaunchKernelGGL((gn_apply_partials<F16>), dim3(nblk, B), dim3(threads), 0, s, (const u16*)x, ldx, (u16*)y, ldy, p1, N1,
+                       p2, N2, rows, gamma, beta, HW, C, groups, eps, rows_per_blk, rpi, silu);
+  else if (dtype == DBIR_BF16)
+    hipLaunchKernelGGL((gn_apply_partials<BF16>), dim3(nblk, B), dim3(threads), 0, s, (const u16*)x, ldx, (u16*)y, ldy, p1, N1,
+                       p2, N2, rows, gamma, beta, HW, C, groups, eps, rows_per_blk, rpi, silu);
+  else {
+    dbir_set_error("dbir_groupnorm_apply_partials: bad dtype");
+    return DBIR_ERR_ARG;
+  }
+  DBIR_CHECK_LAUNCH("dbir_groupnorm_apply_partials");
+  return DBIR_OK;
+}
+
 extern "C" int dbir_groupnorm_from_partials(const float* p1, int N1, const float* p2, int N2, int rows, int B, int HW,
                                             int groups, float eps, const float* gamma, const float* beta, float* mean_var,
                                             float* scale_shift, void* stream) {

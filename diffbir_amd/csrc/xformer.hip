@@ -423,7 +423,7 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
   } while (0)
 
 // DEBUG anatomy (stop_after == 99, debug instantiation only): s_memtime per section, summed over this workgroup's panels,
-// written by wave 0 as 16 x u64 per workgroup into `out` (tools/xf_anatomy.py)
+// written by wave 0 as 16 x u64 per workgroup into `out` (tools/probes/xf_anatomy.py)
 #define XF_TS(I)                                                        \
   do {                                                                  \
     if (DBG == 2) {                                                     \
@@ -436,7 +436,7 @@ __device__ __forceinline__ int xoff(int rowblk, int kst, int col, int lq) {
 // ===============================================================================================================
 // xf_tail
 // ===============================================================================================================
-template <typename T, int DBG, int CC>  // DBG 0 = production, 1 = intermediate dumps (tests), 2 = section timing (tools/xf_anatomy.py)
+template <typename T, int DBG, int CC>  // DBG 0 = production, 1 = intermediate dumps (tests), 2 = section timing (tools/probes/xf_anatomy.py)
 __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   XF_CFG(CC);
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(XNT) void xf_tail_kernel(const XfParams p) {
 
   int issued = 0, consumed = 0, landed = 0, s_slot = 0, c_slot = 0, s_t = 0;
   const char* tbase = smem;
-  // ablation instantiations (wall-clock A/B, tools/xf_anatomy.py): 3 = no staging, 4 = no MFMAs, 5 = no fragment reads
+  // ablation instantiations (wall-clock A/B, tools/probes/xf_anatomy.py): 3 = no staging, 4 = no MFMAs, 5 = no fragment reads
   constexpr int abl = DBG == 3 ? 8 : (DBG == 4 ? 16 : (DBG == 5 ? 32 : 0));
   XF_STAGE(TAIL_TILES);
   XF_STAGE(TAIL_TILES);
@@ -855,7 +855,7 @@ int xf_launch_tail(int dtype, int stop_after, int grid, hipStream_t s, const XfP
     attr_set = true;
   }
   if (stop_after >= 99) {  // section timing (99) / ablations (103 - 105), f16 only, results meaningless
-#ifdef DBIR_DIAG           // only in a `DBIR_DIAG=1 sh build.sh` library (tools/xf_anatomy.py), never in the production ABI
+#ifdef DBIR_DIAG           // only in a `DBIR_DIAG=1 sh build.sh` library (tools/probes/xf_anatomy.py), never in the production ABI
     DBIR_CHECK_ARG(dtype == DBIR_F16, "dbir_xf_tail: the timing instantiations are f16 only");
     if (stop_after == 99) hipLaunchKernelGGL((xf_tail_kernel<F16, 2, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);
     else if (stop_after == 103) hipLaunchKernelGGL((xf_tail_kernel<F16, 3, CC>), dim3(grid), dim3(XNT), XF_LDS, s, p);

@@ -49,6 +49,11 @@ GN_EPI_STATS = os.environ.get("DBIR_GN_EPILOGUE_STATS", "1") != "0"
 # -0.4 ... -0.6 % at batch 8 and batch 4 — the main path's kernels are power- / bandwidth-limited, a kernel beside them takes
 # its time out of theirs.  OFF by default (DBIR_SKIP_SIDE=1 switches it on).
 SKIP_ON_SIDE = os.environ.get("DBIR_SKIP_SIDE", "0") == "1"
+# conv_in (4 / 8 input channels, unet.py:444-448 / controlnet.py:103-107): with the channels padded to 8 (K = 72) only the
+# register-staged generic kernel can run it — 72 us per launch for 1.5 GFLOP (profiles/r4_profile_eval_pair_b8.txt: its
+# 2-byte scattered stores), the slowest launch per FLOP of an evaluation.  Padded to 64 zero channels (K = 576: 12 GFLOP of
+# zeros, a 4 MB input instead of 0.5 MB) it is an ordinary halo-patch / direct-to-LDS convolution.  DBIR_CONV_IN_PAD=8: A/B.
+CONV_IN_PAD = int(os.environ.get("DBIR_CONV_IN_PAD", "64"))
 
 
 def _unique_of_pairs(t: T, pair: Tuple[int, int]) -> T:
@@ -154,7 +159,7 @@ class _DiffusionNet(NativeModule):
         for i, b in enumerate(self.plan.input):
             p = f"input_blocks.{i}"
             if b["kind"] == "conv_in":
-                self.enc.append(("conv_in", self._pk_conv(p + ".0", cin_pad_to=8)))
+                self.enc.append(("conv_in", self._pk_conv(p + ".0", cin_pad_to=CONV_IN_PAD)))
             elif b["kind"] == "res":
                 res = self._pack_res(p + ".0", b["cin"], b["cout"])
                 att = self._pack_attn(p + ".1", b["cout"]) if b["attn"] else None
@@ -353,7 +358,7 @@ class ControlledUnetModel(_DiffusionNet):
             p = f"output_blocks.{i}"
             res = self._pack_res(p + ".0", b["cin"], b["cout"])
             att = self._pack_attn(p + ".1", b["cout"]) if b["attn"] else None
-            up = self._pk_conv(f"{p}.{2 if b['attn'] else 1}.conv") if b["up"] else None
+            up = self._pk_conv(f"{p}.{2 if b['attn'] else 1}.conv", up4=True) if b["up"] else None
             self.dec.append((res, att, up, b))
         self.out_gn = self._pk_norm("out.0")
         self.out_conv = self._pk_conv("out.2")
@@ -381,7 +386,7 @@ class ControlledUnetModel(_DiffusionNet):
         emb_all = self._time_emb(timesteps, t_host)
         x = x.float().contiguous()
         pair = pair if self._pair_ok(pair, x.shape[0]) else None
-        h = ops.nchw_to_nhwc(x if pair is None else _unique_of_pairs(x, pair), None, 8, self._dtype)
+        h = ops.nchw_to_nhwc(x if pair is None else _unique_of_pairs(x, pair), None, CONV_IN_PAD, self._dtype)
         hs, h = self._encode(h, emb_all, ctx_kv, pair)
         if control_ready is not None:
             torch.cuda.current_stream().wait_event(control_ready)
@@ -511,7 +516,7 @@ class ControlNet(_DiffusionNet):
         pair = pair if self._pair_ok(pair, x.shape[0]) else None
         if pair is not None:
             x, hint = _unique_of_pairs(x, pair), _unique_of_pairs(hint, pair)
-        h = ops.nchw_to_nhwc(x, hint, 8, self._dtype)
+        h = ops.nchw_to_nhwc(x, hint, CONV_IN_PAD, self._dtype)
         hs, mid = self._encode(h, emb_all, ctx_kv, pair)
         return hs + [mid]
 

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DBIR_HIP_LIB", os.path.join(_HERE, "libdbir_hip.so"))
 
 F16, BF16 = 0, 1
+ABI_VERSION = 5   # include/dbir.h dbir_abi_version(): checked at load time (a stale libdbir_hip.so must not run silently)
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_LRELU, ACT_GEGLU = 0, 1, 2, 3, 4
 MODE_LINEAR, MODE_CONV3X3 = 0, 1
 
@@ -49,6 +50,7 @@ SIGNATURES = {
     "dbir_groupnorm_stats": [_I, _P, _LL, _I, _I, _I, _I, _P, _P, _P],
     "dbir_groupnorm_apply": [_I, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dbir_groupnorm_from_partials": [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
+    "dbir_groupnorm_apply_partials": [_I, _P, _LL, _P, _LL, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dbir_groupnorm_affine": [_I, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "dbir_layernorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _F, _P],
     "dbir_xf_tile_bytes": [], "dbir_xf_head_tiles": [], "dbir_xf_tail_tiles": [], "dbir_xf_geometry": [_I, _P, _P, _P],
@@ -103,6 +105,10 @@ def lib() -> ctypes.CDLL:
             fn.restype = c_int
         l.dbir_last_error.restype = c_char_p
         l.dbir_last_error.argtypes = []
+        got = int(l.dbir_abi_version())
+        if got != ABI_VERSION:
+            raise NativeError(f"{LIB_PATH} has ABI version {got}, this package needs {ABI_VERSION}: rebuild it "
+                              "(sh diffbir_amd/csrc/build.sh)")
         _lib = l
         v = os.environ.get("DBIR_ATTN_VARIANT")  # A/B switch (include/dbir.h DBIR_OPT_ATTN_VARIANT)
         if v:
@@ -111,6 +117,40 @@ def lib() -> ctypes.CDLL:
         if v:
             check(l.dbir_set_option(2, int(v)), "dbir_set_option")
     return _lib
+
+
+class _CountingLib:
+    """Proxy over the loaded library that counts C-ABI calls (bench.py `launch_path.c_abi_calls_per_eval`)."""
+
+    def __init__(self, l):
+        object.__setattr__(self, "_l", l)
+        object.__setattr__(self, "n", 0)
+
+    def __getattr__(self, name):
+        fn = getattr(self._l, name)
+        if not callable(fn):
+            return fn
+
+        def counted(*a):
+            object.__setattr__(self, "n", self.n + 1)
+            return fn(*a)
+
+        object.__setattr__(self, name, counted)
+        return counted
+
+
+def count_calls(on: bool) -> int:
+    """on=True: start counting every call into the library; on=False: stop and return the count since the start."""
+    global _lib
+    l = lib()
+    if on:
+        if not isinstance(l, _CountingLib):
+            _lib = _CountingLib(l)
+        return 0
+    if isinstance(l, _CountingLib):
+        _lib = l._l
+        return l.n
+    return 0
 
 
 def check(status: int, what: str) -> None:

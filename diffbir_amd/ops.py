@@ -12,6 +12,7 @@ Conventions
   * weights are pre-packed once (`pack_*`) into the `[N_pad, K_pad]` K-contiguous layout the MFMA kernel reads.
 """
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -78,6 +79,7 @@ class PackedWeight:
     n_out: int                # columns actually written
     cin: int = 0              # conv3x3: (padded) input channels
     geglu: bool = False
+    up4: Optional["PackedWeight"] = None   # conv3x3 behind a nearest-x2 upsample: the four parity-collapsed 2x2 weight sets
 
 
 def _finish_pack(w2d: T, bias: Optional[T], dtype, device, n_out=None, cin=0, geglu=False) -> PackedWeight:
@@ -121,8 +123,11 @@ def pack_geglu(w: T, bias: T, dtype, device) -> PackedWeight:
     return _finish_pack(wi, bi, dtype, device, n_out=nh, geglu=True)
 
 
-def pack_conv3x3(w: T, bias: Optional[T], dtype, device, cin_pad_to: int = 8, n_pad_to: int = 1) -> PackedWeight:
-    """Conv2d weight [N, Cin, 3, 3] -> [N, (ky, kx, c)] with Cin zero-padded to a multiple of `cin_pad_to`."""
+def pack_conv3x3(w: T, bias: Optional[T], dtype, device, cin_pad_to: int = 8, n_pad_to: int = 1,
+                 up4: bool = False) -> PackedWeight:
+    """Conv2d weight [N, Cin, 3, 3] -> [N, (ky, kx, c)] with Cin zero-padded to a multiple of `cin_pad_to`.
+    up4: the convolution follows a nearest-x2 upsample (unet.py:76, vae.py:34): also pack the parity-collapsed form
+    (`pack_conv3x3_up4`) when the channel counts allow it."""
     w = w.float()
     N, Cin = w.shape[:2]
     Cp, Np = _rup(Cin, cin_pad_to), _rup(N, n_pad_to)
@@ -132,7 +137,45 @@ def pack_conv3x3(w: T, bias: Optional[T], dtype, device, cin_pad_to: int = 8, n_
         b2 = torch.zeros(Np, dtype=torch.float32, device=w.device)
         b2[:N] = bias.float()
         bias = b2
-    return _finish_pack(w2.reshape(Np, 9 * Cp), bias, dtype, device, cin=Cp)
+    pw = _finish_pack(w2.reshape(Np, 9 * Cp), bias, dtype, device, cin=Cp)
+    if up4 and UP4 and Cp % 32 == 0 and Np == N and N % 8 == 0:
+        pw.up4 = pack_conv3x3_up4(w2, pw.bias, dtype, device)
+    return pw
+
+
+# Nearest-x2 upsample followed by a 3x3 convolution (reference unet.py:51-79 `Upsample`, vae.py:24-36): output pixel
+# (2i + a, 2j + b) only ever sees the 2x2 low-resolution neighbourhood (i + a - 1 .., j + b - 1 ..), and the 3x3 taps that
+# land on the same low-resolution pixel can be summed ahead of time: row taps {ky} -> a = 0: [W0], [W1 + W2]; a = 1:
+# [W0 + W1], [W2] (same for columns).  Four 2x2 convolutions (one per output parity) replace one 3x3 convolution on a 4x
+# larger grid: 16 instead of 36 multiplies per low-resolution pixel and channel pair — 4 / 9 of the work, exact algebra
+# (the only numerical difference: the f32 tap sums are rounded to 16 bit once, instead of each tap being rounded).
+# DBIR_UP4=0 keeps the upsampled 3x3 gather (A/B).
+UP4 = os.environ.get("DBIR_UP4", "1") != "0"
+_UP4_TAPS = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}   # (parity, low-res tap) -> 3x3 taps
+
+
+def up4_weights(w_khwc: T) -> T:
+    """[N, 3, 3, C] f32 -> [4 (parity a * 2 + b), N, 2 (ty), 2 (tx), C] f32 tap sums."""
+    N, _, _, C = w_khwc.shape
+    w4 = torch.zeros((4, N, 2, 2, C), dtype=torch.float32, device=w_khwc.device)
+    for a in range(2):
+        for b in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    for ky in _UP4_TAPS[(a, ty)]:
+                        for kx in _UP4_TAPS[(b, tx)]:
+                            w4[2 * a + b, :, ty, tx] += w_khwc[:, ky, kx]
+    return w4
+
+
+def pack_conv3x3_up4(w_khwc: T, bias_f32: Optional[T], dtype, device) -> PackedWeight:
+    """[N, 3, 3, Cin] (Cin % 32 == 0) -> PackedWeight whose `w` is [4 * Wrows, 4 * Cin]: four [Wrows, (ty, tx, c)] matrices."""
+    N, _, _, C = w_khwc.shape
+    w4 = up4_weights(w_khwc.float())
+    Wrows, K = _rup(N, 128), 4 * C
+    buf = torch.zeros((4, Wrows, K), dtype=dtype, device=device)
+    buf[:, :N] = w4.reshape(4, N, K).to(device=device, dtype=dtype)
+    return PackedWeight(buf.reshape(4 * Wrows, K), bias_f32, N, K, K, N, C)
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
@@ -173,8 +216,11 @@ class _Timed:
 
 @dataclass
 class GnPartials:
-    """Column sums of a GEMM output emitted by its epilogue (dbir_gemm_desc.stats): buf f32 [M / rows, 2, N] — per tile of
-    `rows` rows and column: sum and sum of squares of the stored 16-bit values.  Consumed by groupnorm(..., stats=...)."""
+    """Column statistics of a GEMM output emitted by its epilogue (dbir_gemm_desc.stats, ABI >= 4): buf f32 [M / rows, 2, N] —
+    per tile of `rows` rows and column: [0] the SUM of the stored 16-bit values, [1] their M2 = the sum of squared deviations
+    from that tile-column's own mean (NOT the sum of squares: merge tiles with Chan's parallel-variance formula, as
+    csrc/norm.hip gn_from_partials / gn_apply_partials do).  Every tile lies inside one sample; the tiles of a sample are
+    adjacent rows of `buf` (in any order).  Consumed by groupnorm(..., stats=...)."""
     buf: T
     rows: int
     N: int
@@ -221,7 +267,8 @@ def apply_tile_code(d: GemmDesc, code: int, device) -> None:
     d.tile, sk = code % 100, code // 100
     if sk > 1:
         if d.tile == 80:   # in-launch reduce: whole 256 x 320 accumulator slabs per (tile, slice) + arrival counters
-            tiles = ((d.M + 255) // 256) * ((d.N + 319) // 320)
+            mt = 4 * ((d.M // 4 + 255) // 256) if d.upsample == 2 else (d.M + 255) // 256   # (up4: row tiles per parity)
+            tiles = mt * ((d.N + 319) // 320)
             nbytes = tiles * sk * 256 * 320 * 4 + tiles * 4 + 256
         else:
             nbytes = sk * max(d.batch, 1) * d.M * d.N * 4
@@ -234,6 +281,8 @@ def apply_tile_code(d: GemmDesc, code: int, device) -> None:
 def _gemm_launch(d: GemmDesc, keep):
     out = keep[2]
     from_table = False
+    if d.tile == 0 and d.upsample == 2:
+        raise native.NativeError("conv3x3: the parity-collapsed upsample convolution needs an explicit tile-80 code")
     if d.tile == 0:
         if _TUNER is not None:
             code = _TUNER.run(d, out)
@@ -251,7 +300,7 @@ def _gemm_launch(d: GemmDesc, keep):
     tag = ""
     if _PROFILE is not None:
         tag = (f"{'conv' if d.mode == MODE_CONV3X3 else 'lin'} M{d.M} N{d.N} K{d.K} z{max(d.batch, 1)} act{d.act}"
-               f"{' s2' if d.stride == 2 else ''}{' up' if d.upsample else ''}{' T' if d.store_mode else ''}"
+               f"{' s2' if d.stride == 2 else ''}{(' up4' if d.upsample == 2 else ' up') if d.upsample else ''}{' T' if d.store_mode else ''}"
                f"{' f32' if d.out_f32 else ''}{' res' if d.R else ''} t{d.tile}{'k%d' % d.splitk if d.splitk > 1 else ''}")
     # algorithmic HBM bytes: every operand once (conv input once, not once per tap), 16-bit
     z = max(d.batch, 1)
@@ -347,11 +396,34 @@ def conv3x3(x: T, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: boo
     d.W, d.Wrows, d.Kpad = pw.w.data_ptr(), pw.w.shape[0], pw.Kpad
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo = B, Hi, Wi, Cin, Ho, Wo
     d.stride, d.pad, d.upsample = stride, pad, int(upsample)
+    if upsample and _up4_ok(pw, x, out, stride, pad, out_hw, residual, rowvec, out_f32, tile):
+        # parity-collapsed form (pack_conv3x3_up4): four 2x2 convolutions on the low-resolution grid, tile 80 only
+        u = pw.up4
+        d.K, d.W, d.Wrows, d.Kpad, d.upsample = u.K, u.w.data_ptr(), u.w.shape[0] // 4, u.Kpad, 2
+        if tile == 0:   # one 256 x 320 tile per (parity, 256 low-resolution pixels, 320 columns); split K to fill the chip
+            tiles = 4 * ((B * Hi * Wi + 255) // 256) * ((pw.N + 319) // 320)
+            sk = 1 if tiles >= 192 else min(max(256 // tiles, 1), max(u.K // 32 // 16, 1))
+            tile = 80 + (100 * sk if sk > 1 else 0)
+        keep_w = u
+    else:
+        keep_w = pw
     _fill_epilogue(d, pw, act, act_param, out_scale, residual, rowvec, Ho * Wo, out, out_f32)
     apply_tile_code(d, tile, x.device)  # tile id, or tile + 100 * split-K slices
     st = _stats_begin(d, stats, B * Ho * Wo, pw.N, x.device)
-    _gemm_launch(d, (x, pw, out, residual, rowvec, st))
+    _gemm_launch(d, (x, keep_w, out, residual, rowvec, st))
     return (out, _stats_end(d, st, B * Ho * Wo, pw.N)) if stats else out
+
+
+def _up4_ok(pw: PackedWeight, x: T, out: T, stride, pad, out_hw, residual, rowvec, out_f32, tile) -> bool:
+    """Can this upsampled convolution run in the parity-collapsed form?  (mirrors dbir_gemm_8p_eligible)"""
+    if pw.up4 is None or not UP4 or stride != 1 or pad != 1 or out_hw is not None or residual is not None \
+            or rowvec is not None or out_f32 or (tile % 100) not in (0, 80):
+        return False
+    _, Hi, Wi, _ = x.shape
+    if Hi & (Hi - 1) or Wi & (Wi - 1):
+        return False
+    ldc = _ld(out)
+    return ldc % 8 == 0 and out.data_ptr() % 16 == 0 and (_rows(out) - 1) * ldc + pw.N < (1 << 30)
 
 
 def bmm_nt(a: T, b: T, out: T, out_scale: float = 1.0) -> T:
@@ -465,6 +537,14 @@ def groupnorm_stats_from_partials(parts, B: int, HW: int, groups: int, eps: floa
     return ab if affine else mv
 
 
+# the statistics merge of the epilogue partials inside the normalising kernel (dbir_groupnorm_apply_partials) instead of a
+# launch of its own in front of it.  MEASURED SLOWER and therefore OFF (DBIR_GN_FUSED_PARTIALS=1 switches it on): every block
+# of the normalising launch repeats the merge of its sample's ~5000 scattered (sum, M2) cells in two dependent passes before
+# its first row — 6.69 img/s with the separate 5 us merge launch vs 6.47 - 6.53 fused, same box, interleaved
+# (profiles/r5_call1_ab.txt).  Kept, with its parity test, as the measured counter-example to "fold every small launch".
+GN_FUSED_PARTIALS = os.environ.get("DBIR_GN_FUSED_PARTIALS", "0") == "1"
+
+
 def groupnorm(x: T, gamma: T, beta: T, eps: float, silu: bool, out: Optional[T] = None, groups: int = 32,
               stats=None) -> T:
     """x: [B, H, W, C] (or [B, HW, C]) 16-bit; gamma/beta f32 [C].
@@ -474,6 +554,15 @@ def groupnorm(x: T, gamma: T, beta: T, eps: float, silu: bool, out: Optional[T] 
     B, C = x.shape[0], x.shape[-1]
     HW = _rows(x) // B
     parts = _usable_partials(stats, B, HW, C)
+    if parts is not None and GN_FUSED_PARTIALS:
+        p1, p2 = parts
+        if out is None:
+            out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        native.check(native.lib().dbir_groupnorm_apply_partials(
+            _dt(x), x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), gamma.data_ptr(), beta.data_ptr(), p1.buf.data_ptr(), p1.N,
+            None if p2 is None else p2.buf.data_ptr(), 0 if p2 is None else p2.N, p1.rows, B, HW, groups, eps, int(silu),
+            _stream()), "dbir_groupnorm_apply_partials")
+        return out
     if parts is not None:
         mv = groupnorm_stats_from_partials(parts, B, HW, groups, eps)
         return groupnorm_apply(x, gamma, beta, mv, eps, silu, out=out, groups=groups)

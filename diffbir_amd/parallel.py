@@ -38,15 +38,32 @@ class DistContext:
     group: Optional[object] = None
     _noise: Optional[Callable] = None   # persistent shared-seed noise stream of run_data_parallel
     _tree_seeds: Optional[torch.Generator] = None   # shared-seed source of the SDE solvers' Brownian-tree seeds
+    force: bool = False                 # issue the collectives even with ONE rank (see `multi`)
 
     @property
     def is_main(self) -> bool:
         return self.rank == 0
 
+    @property
+    def multi(self) -> bool:
+        """Do the collectives run?  world > 1, or a single rank with `force` (DBIR_FORCE_COLLECTIVES=1 /
+        init_distributed(force=True)): the 1-GPU box then executes the very RCCL calls an 8-GPU node makes — communicator
+        init, bucketed broadcast, all-reduce per evaluation, gather — on a one-rank communicator (library load, stream
+        ordering, IPC set-up; results must be bit-identical to the plain single-process run: tests/test_multigpu_gpu.py)."""
+        return self.world > 1 or self.force
 
-def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None) -> DistContext:
+
+# collectives issued through this module since import (bench.py reports them: `rccl.calls`)
+calls = dict(broadcast=0, all_reduce=0, gather=0, new_group=0)
+
+
+def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None,
+                     force: Optional[bool] = None) -> DistContext:
     """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun).
-    backend None -> "nccl" (RCCL) when a GPU is visible, else "gloo".  world == 1 needs no process group."""
+    backend None -> "nccl" (RCCL) when a GPU is visible, else "gloo".  world == 1 needs no process group — unless `force`
+    (default: env DBIR_FORCE_COLLECTIVES=1), which creates the one-rank group and makes every collective below run."""
+    if force is None:
+        force = os.environ.get("DBIR_FORCE_COLLECTIVES", "0") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -56,12 +73,13 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
             device = torch.device("cuda", local)
         else:
             device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         be = backend or ("nccl" if device.type == "cuda" else "gloo")
         kw = dict(device_id=device) if be == "nccl" else {}
         dist.init_process_group(be, rank=rank, world_size=world, **kw)
-    return DistContext(rank, world, device)
+    return DistContext(rank, world, device, force=bool(force))
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -113,7 +131,8 @@ def all_reduce_sum(ctx: DistContext) -> Callable:
     """tensor -> tensor summed over ranks (in place; RCCL all-reduce on the tensor's device)."""
 
     def fn(t: torch.Tensor) -> torch.Tensor:
-        if ctx.world > 1:
+        if ctx.multi:
+            calls["all_reduce"] += 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=ctx.group)
         return t
 
@@ -126,7 +145,7 @@ def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], spec, ctx: DistC
     (model/specs.py) so receivers know names / shapes without a handshake.  Tensors travel as f32 in flat buckets of
     `bucket_bytes` (few large RCCL broadcasts instead of ~3000 small ones: xGMI links are point-to-point, per-message
     latency dominates small transfers)."""
-    if ctx.world == 1:
+    if not ctx.multi:
         return sd
     keys = [k for k, (_, kind) in spec.items() if kind != "buf"]
     out: Dict[str, torch.Tensor] = {}
@@ -143,6 +162,7 @@ def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], spec, ctx: DistC
                 m = int(np.prod(spec[k][0]))
                 flat[off:off + m] = sd[k].reshape(-1).to(device=ctx.device, dtype=torch.float32)
                 off += m
+        calls["broadcast"] += 1
         dist.broadcast(flat, src=src, group=ctx.group)
         off = 0
         for k in keys[i:j]:
@@ -155,13 +175,14 @@ def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], spec, ctx: DistC
 
 def gather_batch(local: np.ndarray, batch: int, ctx: DistContext, dst: int = 0) -> Optional[np.ndarray]:
     """uint8 [b_r, H, W, 3] slices -> [B, H, W, 3] on rank `dst` (None elsewhere)."""
-    if ctx.world == 1:
+    if not ctx.multi:
         return local
     bmax = shard_range(batch, 0, ctx.world)
     bmax = bmax[1] - bmax[0]
     t = torch.zeros((bmax,) + local.shape[1:], dtype=torch.uint8, device=ctx.device)
     t[: local.shape[0]] = torch.as_tensor(local).to(ctx.device)
     bufs = [torch.empty_like(t) for _ in range(ctx.world)] if ctx.rank == dst else None
+    calls["gather"] += 1
     dist.gather(t, bufs, dst=dst, group=ctx.group)
     if ctx.rank != dst:
         return None
@@ -182,7 +203,7 @@ def enable_tile_sharding(pipe, ctx: DistContext, seed: Optional[int] = 231, chec
     additionally all-reduces a checksum of the blended prediction every n evaluations and raises if the ranks' inputs
     have diverged (debug aid: one extra 8-byte all-reduce)."""
     vae = getattr(getattr(pipe, "cldm", None), "vae", None)
-    if ctx.world <= 1:
+    if not ctx.multi:
         pipe.tile_shard, pipe.tile_all_reduce = None, None
         if vae is not None:
             vae.tile_shard, vae.tile_all_reduce = None, None
@@ -240,24 +261,26 @@ def hybrid_split(ctx: DistContext, n_images: int) -> Tuple[DistContext, int, int
     g, r = ctx.rank // S, ctx.rank % S
     per = n_images // G
     group = None
-    if ctx.world > 1 and S > 1:
+    if (ctx.world > 1 and S > 1) or ctx.force:
         for gi in range(G):   # new_group is collective: every rank creates every group, keeps its own
+            calls["new_group"] += 1
             h = dist.new_group(list(range(gi * S, (gi + 1) * S)))
             if gi == g:
                 group = h
-    return DistContext(r, S, ctx.device, group), g * per, (g + 1) * per
+    return DistContext(r, S, ctx.device, group, force=ctx.force), g * per, (g + 1) * per
 
 
 def gather_group_outputs(local: Optional[np.ndarray], n_images: int, ctx: DistContext, sub: DistContext,
                          dst: int = 0) -> Optional[np.ndarray]:
     """After a hybrid run every rank of a group holds the group's restored images: the group leaders' slices -> rank
     `dst` in image order (RCCL gather over the WORLD group; the other ranks of a group contribute nothing)."""
-    if ctx.world == 1:
+    if not ctx.multi:
         return local
     G = ctx.world // sub.world
     per = n_images // G
     t = torch.as_tensor(local).to(ctx.device).contiguous()
     bufs = [torch.empty_like(t) for _ in range(ctx.world)] if ctx.rank == dst else None
+    calls["gather"] += 1
     dist.gather(t, bufs, dst=dst, group=ctx.group)
     if ctx.rank != dst:
         return None
@@ -318,7 +341,7 @@ def run_data_parallel(pipe, lq: np.ndarray, ctx: DistContext, run_args: tuple, n
         noise = ctx._noise
     base = noise
     prev, prev_b = pipe.randn, pipe.brownian
-    pipe.randn = ShardedNoise(base, B, lo, hi) if ctx.world > 1 else base
+    pipe.randn = ShardedNoise(base, B, lo, hi) if ctx.multi else base
     if prev_b is None:
         # the SDE solvers' Brownian tree: one seed per call from a generator every rank seeds alike (drawn whether or not
         # this call uses an SDE solver or this rank has rows, so the ranks stay in step), full-batch tree, this rank's rows

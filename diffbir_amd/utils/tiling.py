@@ -32,7 +32,9 @@ class TiledModel:
         self.forward, self.ts, self.stride, self.max_batch = forward, tile_size, tile_stride, max_batch
         if shard is not None and shard[1] > 1 and all_reduce is None:
             raise ValueError("tile sharding over >1 ranks needs an all_reduce callable (diffbir_amd.parallel)")
-        self.shard = shard if (shard is not None and shard[1] > 1) else None
+        # (one rank WITH an all_reduce = parallel's forced-collectives mode: the sharded path — partial sum, all-reduce over a
+        #  one-rank communicator, normalise — runs as on N GPUs; same f32 operations in the same order as the plain path)
+        self.shard = shard if (shard is not None and (shard[1] > 1 or all_reduce is not None)) else None
         self.all_reduce = all_reduce
         self._den: Dict[tuple, T] = {}
         self._coords: Dict[tuple, T] = {}

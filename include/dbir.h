@@ -38,7 +38,8 @@ const char* dbir_last_error(void);
 /* 3 since round 3: dbir_gemm takes a non-const descriptor (stats / stats_rows fields at its end), dbir_xf_head / dbir_xf_tail /
  * dbir_xf_geometry, dbir_groupnorm_affine, dbir_groupnorm_from_partials; tiles 80 - 89 retired, 90 - 92 added.
  * 4 since round 4: dbir_gemm_desc.stats holds [sum, M2] per (row tile, column) instead of [sum, sum of squares] (and
- * dbir_groupnorm_from_partials reads that), split-K launches emit them; tile 80 = the fine-phase 256x320 kernel. */
+ * dbir_groupnorm_from_partials reads that), split-K launches emit them; tile 80 = the fine-phase 256x320 kernel.
+ * 5 since round 5: dbir_gemm_desc.upsample == 2 (parity-collapsed upsample convolution), dbir_groupnorm_apply_partials. */
 int dbir_abi_version(void);
 /* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 2 (default) = LDS-resident
  * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape, 4 / 5 =
@@ -63,6 +64,11 @@ int dbir_set_option(int key, int value);
  *   mode CONV3X3: A is an NHWC 16-bit tensor [B, Hi, Wi, Cin] (Cin % 8 == 0); output pixel (b,oy,ox) is row
  *                 m = (b*Ho + oy)*Wo + ox; reduction index k = (ky*3+kx)*Cin + c; input coordinate
  *                 iy = oy*stride - pad + ky (same for x) in the (optionally nearest-x2 upsampled) input.
+ *                 upsample == 2 (tile 80 only, round 5): the same nearest-x2 upsample + 3x3 convolution (stride 1, pad 1,
+ *                 Hi / Wi powers of two) evaluated as FOUR 2x2 convolutions on the low-resolution input, one per output
+ *                 parity (a, b): out[b, 2i+a, 2j+b] = sum_{ty,tx,c} in[b, i+a-1+ty, j+b-1+tx, c] * W[2a+b][n][(ty*2+tx)*Cin+c],
+ *                 where W[2a+b] holds the 3x3 taps that land on each low-resolution pixel summed in f32 (4 / 9 of the
+ *                 multiplies, exact algebra): K = 4 * Cin, W = [4][Wrows][Kpad]; no residual / row vector.
  *   W           : 16-bit [Wrows, Kpad] row-major (row n = output column n), Kpad % 64 == 0, zero padded.
  *   epilogue    : v = acc + bias[n] + rowvec[(m / rows_per_batch) * rowvec_ld + n]; v = act(v);
  *                 v = v * out_scale + R[m*ldr + n]; store.
@@ -198,6 +204,11 @@ int dbir_groupnorm_affine(int dtype, const void* x, long long ldx, int B, int HW
 int dbir_groupnorm_from_partials(const float* p1, int N1, const float* p2, int N2, int rows, int B, int HW, int groups,
                                  float eps, const float* gamma, const float* beta, float* mean_var, float* scale_shift,
                                  void* stream);
+/* dbir_groupnorm_apply_partials (round 5): dbir_groupnorm_from_partials + dbir_groupnorm_apply in one launch — every block
+ * merges the (sum, M2) cells of its sample itself (same f64 merge), then normalises (+ SiLU) its rows of x [B, HW, N1 + N2]. */
+int dbir_groupnorm_apply_partials(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,
+                                  const float* beta, const float* p1, int N1, const float* p2, int N2, int rows, int B, int HW,
+                                  int groups, float eps, int silu, void* stream);
 /* dbir_layernorm: nn.LayerNorm rows (attention.py:255-257; swinir.py:205,211,764), eps 1e-5.
  * Normalises over the first C columns; columns [C, Cpad) of y are written as zero. */
 int dbir_layernorm(int dtype, const void* x, long long ldx, void* y, long long ldy, const float* gamma,

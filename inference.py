@@ -12,7 +12,7 @@ and `--version v1 | v2 | v2.1 | custom` run on the engine (SwinIR / BSRNet / SCU
 import os
 from argparse import ArgumentParser, Namespace
 
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before torch initialises HIP (diffbir_amd/__init__.py says why)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # a default for an UNSET variable, before torch initialises HIP (diffbir_amd/__init__.py)
 
 import torch  # noqa: E402
 

@@ -78,6 +78,9 @@ class OraclePipeline:
             c_txt=nets.clip_text_encode(self.W["clip"], self.cldm_cfg["clip_cfg"], self.tokenize(txt)),
             c_img=nets.vae_encode_mode(self.W["vae"], self.cldm_cfg["vae_cfg"], img * 2 - 1, self.scale_factor))
 
+    def vae_decode(self, z: T) -> T:
+        return nets.vae_decode(self.W["vae"], self.cldm_cfg["vae_cfg"], z, self.scale_factor)
+
     def cleaner(self, x: T) -> T:
         return nets.swinir_forward(self.W["swinir"], self.swinir_cfg, x)
 
@@ -139,7 +142,7 @@ class OraclePipeline:
         z = z[..., :h1, :w1]
         if taps is not None:
             taps.update(z=z.clone())
-        x = nets.vae_decode(self.W["vae"], self.cldm_cfg["vae_cfg"], z, self.scale_factor)
+        x = self.vae_decode(z)
         self.control_scales = saved
         return x[:, :, :h0, :w0]
 

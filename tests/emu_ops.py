@@ -108,6 +108,28 @@ def conv3x3(x, pw, stride=1, pad=1, upsample=False, out=None, act=ACT_NONE, act_
     return out
 
 
+def conv3x3_up4(x, pw, out=None, act=ACT_NONE, act_param=0.0, out_scale=1.0):
+    """The parity-collapsed statement of nearest-x2 upsample + conv3x3 on the PACKED up4 weights (ops.pack_conv3x3_up4):
+    out[b, 2i+a, 2j+c] = sum_{ty,tx} x[b, i+a-1+ty, j+c-1+tx] . W[2a+c][:, ty, tx]  (zero outside the input)."""
+    u = pw.up4
+    B, Hi, Wi, Cin = x.shape
+    N, Wrows = u.N, u.w.shape[0] // 4
+    w4 = u.w.float().reshape(4, Wrows, 2, 2, Cin)[:, :N].permute(0, 1, 4, 2, 3)          # [4, N, Cin, 2, 2]
+    xi = F.pad(x.float().permute(0, 3, 1, 2), (1, 1, 1, 1))                               # low-res pixel (i, j) at (i+1, j+1)
+    y = torch.zeros((B, N, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
+    for a in range(2):
+        for c in range(2):
+            full = F.conv2d(xi, w4[2 * a + c])                                            # [B, N, Hi+1, Wi+1], (r, s) <-> taps (r.., s..)
+            y[:, :, a::2, c::2] = full[:, :, a:a + Hi, c:c + Wi]
+    acc = y.permute(0, 2, 3, 1).reshape(B * 4 * Hi * Wi, N)
+    res = _epilogue(acc, pw, act, act_param, out_scale, None, None, 4 * Hi * Wi)[:, : pw.n_out]
+    res = res.to(x.dtype).reshape(B, 2 * Hi, 2 * Wi, pw.n_out)
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
 def bmm_nt(a, b, out, out_scale=1.0):
     out.copy_((torch.bmm(a.float(), b.float().transpose(1, 2)) * out_scale).to(out.dtype))
     return out

@@ -53,3 +53,12 @@ def test_gpus_flag_self_spawns_and_checks_world_size():
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--selftest"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_forced_collectives_on_one_rank():
+    """`--force-collectives` (the mode tests/test_multigpu_gpu.py runs over RCCL on the 1-GPU box): a ONE-rank process group is
+    created and the broadcast / barrier / max-over-ranks all-reduce / gather all execute on it."""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+              "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1",
+              "--selftest", "--force-collectives"])
+    assert REQUIRED <= set(r) and r["n_gpus"] == 1 and r.get("broadcast_checked") is True and r["gathered_batch"][0] == 8

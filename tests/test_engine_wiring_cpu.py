@@ -98,7 +98,7 @@ def test_ddim_edm_samplers_vs_reference_golden(monkeypatch, golden_dir, name):
 
 
 @pytest.mark.parametrize("name", sorted(SAMPLER_TREE_CASES))
-def test_sde_samplers_on_brownian_tree_vs_reference_golden(monkeypatch, golden_dir, name):
+def test_sde_samplers_on_brownian_tree_vs_refshim_golden(monkeypatch, golden_dir, name):
     """The three SDE solvers with the engine's own Brownian tree (sampler/brownian.py) against the unmodified reference running
     its BrownianTreeNoiseSampler / BatchedBrownianTree (k_diffusion.py:70-119) on the restated torchsde tree of
     oracle/refshim/torchsde: seed draw, sigma range, per-solver query times, sign / normalisation and the tree itself."""

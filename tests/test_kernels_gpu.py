@@ -764,6 +764,75 @@ def test_8p_conv3x3(B, H, W, Cin, N, stride, pad, ups, ohw, dtype):
     check(f"8p conv3x3 {B}x{H}x{W}x{Cin}->{N} s{stride} p{pad} u{int(ups)}", got, ref.to(dtype), dtype)
 
 
+UP4_CASES = [
+    # B, Hi, Wi, Cin, N, tile code (0 = the op's own choice)
+    (2, 16, 16, 160, 96, 0), (16, 8, 8, 1280, 1280, 0), (4, 32, 32, 640, 640, 0), (3, 8, 8, 64, 320, 80), (1, 4, 4, 32, 8, 80),
+    (16, 16, 16, 1280, 1280, 0), (2, 8, 16, 96, 648, 280), (5, 4, 8, 64, 40, 380),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Hi,Wi,Cin,N,code", UP4_CASES)
+def test_8p_conv_up4(B, Hi, Wi, Cin, N, code, dtype):
+    """Parity-collapsed nearest-x2 upsample + 3x3 convolution (gemm_8p.hip PH4, ops.pack_conv3x3_up4): against the
+    statement on the SAME packed tap sums (kernel check, GEMM tolerance), against the reference's op sequence
+    F.interpolate(nearest) -> conv2d on the unpacked weight (the tap sums are rounded once instead of per tap: 2x the
+    tolerance), and against the upsampled 3x3 gather of the same engine (DBIR_UP4 off)."""
+    x = rnd(B, Hi, Wi, Cin, dtype=dtype)
+    w = rnd(N, Cin, 3, 3, dtype=torch.float32, s=(9 * Cin) ** -0.5, seed=1)
+    b = rnd(N, dtype=torch.float32, seed=2)
+    pw = ops.pack_conv3x3(w.cpu(), b.cpu(), dtype, DEV, up4=True)
+    assert pw.up4 is not None
+    big = torch.zeros(B, 2 * Hi, 2 * Wi, N + 24, dtype=dtype, device=DEV)
+    got = ops.conv3x3(x, pw, upsample=True, tile=code, out=big[..., 8:8 + N])
+    assert (big[..., :8] == 0).all() and (big[..., 8 + N:] == 0).all(), "wrote outside the output view"
+    check(f"up4 {B}x{Hi}x{Wi}x{Cin}->{N} c{code} vs packed statement", got, emu.conv3x3_up4(x, pw), dtype)
+    xi = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(xi, w.to(dtype).float(), b, padding=1).permute(0, 2, 3, 1)
+    check(f"up4 {B}x{Hi}x{Wi}x{Cin}->{N} vs interpolate+conv2d", got, ref.to(dtype), dtype, scale=2.0)
+    pw3 = ops.pack_conv3x3(w.cpu(), b.cpu(), dtype, DEV)
+    check("up4 vs upsampled 3x3 gather", got, ops.conv3x3(x, pw3, upsample=True), dtype, scale=2.0)
+    for _ in range(2):
+        assert torch.equal(got, ops.conv3x3(x, pw, upsample=True, tile=code, out=torch.zeros_like(big)[..., 8:8 + N]))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_8p_conv_up4_epilogue_and_statistics(dtype):
+    """Activation + scale in the epilogue; GroupNorm column statistics of the scattered output rows (the tiles of a sample:
+    4 parities x its low-resolution row tiles, adjacent statistics rows) incl. the in-launch split-K reduction; shapes the
+    collapsed form cannot run fall back to the upsampled gather."""
+    B, Hi, Wi, Cin, N = 3, 16, 16, 128, 320
+    x = rnd(B, Hi, Wi, Cin, dtype=dtype)
+    pw = ops.pack_conv3x3(rnd(N, Cin, 3, 3, dtype=torch.float32, s=(9 * Cin) ** -0.5, seed=1).cpu(),
+                          rnd(N, dtype=torch.float32, seed=2).cpu(), dtype, DEV, up4=True)
+    kw = dict(act=emu.ACT_LRELU, act_param=0.2, out_scale=0.7)
+    check("up4 lrelu+scale", ops.conv3x3(x, pw, upsample=True, **kw), emu.conv3x3_up4(x, pw, **kw), dtype)
+    for code in (0, 80, 280, 480):
+        out, st = ops.conv3x3(x, pw, upsample=True, stats=True, tile=code)
+        assert st is not None and st.rows == 256 and st.M == B * 4 * Hi * Wi, (code, st)
+        check(f"up4 stats out c{code}", out, emu.conv3x3_up4(x, pw), dtype)
+        mv = ops.groupnorm_stats_from_partials((st, None), B, 4 * Hi * Wi, 32, 1e-5)
+        o = out.double().reshape(B, 4 * Hi * Wi, 32, N // 32)
+        mean, var = o.mean((1, 3)), o.var((1, 3), unbiased=False)
+        assert ((mv[:, :32].double() - mean).abs() / (mean.abs() + 1.0)).max().item() < 1e-5, code
+        assert ((mv[:, 32:].double() - var).abs() / var).max().item() < 5e-4, code
+        gn = ops.groupnorm(out, torch.ones(N, device=DEV), torch.zeros(N, device=DEV), 1e-5, True, stats=st)
+        check(f"up4 groupnorm from partials c{code}", gn, emu.groupnorm(out, torch.ones(N, device=DEV),
+                                                                           torch.zeros(N, device=DEV), 1e-5, True), dtype)
+    # 8x8 low-resolution grid: 64 pixels per sample < one 256-row tile -> no statistics from this launch
+    x8 = rnd(4, 8, 8, Cin, dtype=dtype, seed=5)
+    o8, st8 = ops.conv3x3(x8, pw, upsample=True, stats=True)
+    assert st8 is None
+    check("up4 8x8", o8, emu.conv3x3_up4(x8, pw), dtype)
+    # not a power of two: the op falls back to the upsampled gather (same result within tolerance)
+    x12 = rnd(2, 12, 20, Cin, dtype=dtype, seed=6)
+    check("up4 fallback 12x20", ops.conv3x3(x12, pw, upsample=True), emu.conv3x3(x12, pw, upsample=True), dtype)
+    res = rnd(2, 32, 32, N, dtype=dtype, seed=7)
+    x16 = rnd(2, 16, 16, Cin, dtype=dtype, seed=8)
+    check("up4 fallback residual", ops.conv3x3(x16, pw, upsample=True, residual=res),
+          emu.conv3x3(x16, pw, upsample=True, residual=res), dtype)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_8p_conv3x3_fused_epilogue_and_splitk(dtype):
     """time-embedding row vector + strided residual into a concat-buffer view; split-K inside the launch (2 = own + other,
@@ -1074,6 +1143,44 @@ def test_groupnorm(B, HW, C, silu, eps, dtype):
     ops.groupnorm(wide[..., 64:], g, b, eps, silu, out=oa[..., :C])
     emu.groupnorm(wide[..., 64:], g, b, eps, silu, out=ob[..., :C])
     check("groupnorm strided", oa, ob, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cl,Cr,silu,code", [(2, 64, 64, 320, 0, True, 14), (3, 16, 16, 1280, 1280, True, 205),
+                                                    (2, 32, 32, 640, 320, False, 5), (16, 16, 16, 1280, 0, True, 80)])
+def test_groupnorm_fused_partials(B, H, W, Cl, Cr, silu, code, dtype, monkeypatch):
+    """dbir_groupnorm_apply_partials (statistics merge inside the normalising kernel, round 5) against the two-launch form
+    (dbir_groupnorm_from_partials -> dbir_groupnorm_apply) on the same epilogue partials — one or two column-adjacent
+    producers (decoder concat buffer), 256-row tiles and the 64-row tiles of a split-K reduce pass — and against the f32
+    statement of GroupNorm on the stored tensor."""
+    C = Cl + Cr
+    buf = torch.zeros(B, H, W, C, dtype=dtype, device=DEV)
+    K = 128
+    a = rnd(B * H * W, K, dtype=dtype, seed=11) + 0.4
+    parts = []
+    for (c0, n, seed) in [(0, Cl, 1), (Cl, Cr, 2)]:
+        if n == 0:
+            continue
+        pw = ops.pack_linear(rnd(n, K, dtype=torch.float32, s=K ** -0.5, seed=seed).cpu(),
+                             (1.5 * rnd(n, dtype=torch.float32, seed=seed + 2)).cpu(), dtype, DEV)
+        _, st = ops.linear(a, pw, out=buf.reshape(B * H * W, C)[:, c0:c0 + n], stats=True, tile=code)
+        assert st is not None, (c0, n, code)
+        parts.append(st)
+    stats = parts[0] if len(parts) == 1 else tuple(parts)
+    assert ops._usable_partials(stats, B, H * W, C) is not None, [(q.rows, q.N, q.M) for q in parts]
+    g, b = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=5), 0.1 * rnd(C, dtype=torch.float32, seed=6)
+    monkeypatch.setattr(ops, "GN_FUSED_PARTIALS", True)
+    fused = ops.groupnorm(buf, g, b, 1e-5, silu, stats=stats)
+    monkeypatch.setattr(ops, "GN_FUSED_PARTIALS", False)
+    two = ops.groupnorm(buf, g, b, 1e-5, silu, stats=stats)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    d = (fused.float() - two.float()).abs()
+    assert (d <= 1.01 * ulp * two.float().abs() + 1e-6).all(), f"fused vs two-launch: {d.max().item():.3e}"
+    check(f"groupnorm fused partials B{B} {H}x{W} C{Cl}+{Cr}", fused, emu.groupnorm(buf, g, b, 1e-5, silu), dtype)
+    wide = torch.zeros(B, H, W, C + 16, dtype=dtype, device=DEV)
+    monkeypatch.setattr(ops, "GN_FUSED_PARTIALS", True)
+    ops.groupnorm(buf, g, b, 1e-5, silu, stats=stats, out=wide[..., 8:8 + C])
+    assert torch.equal(wide[..., 8:8 + C], fused) and (wide[..., :8] == 0).all() and (wide[..., 8 + C:] == 0).all()
 
 
 def test_groupnorm_large_offset_small_spread():

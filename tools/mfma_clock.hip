@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
     run<1, 8>(names[fill], fill, 1, iters);
     run<1, 8>(names[fill], fill, 2, iters);
   }
-  run<0, 4>(names[3], 3, 1, iters);   // the 4-chain loop of tools/mfma_valu_overlap.hip for comparison
+  run<0, 4>(names[3], 3, 1, iters);   // the 4-chain loop of tools/probes/mfma_valu_overlap.hip for comparison
   run<0, 4>(names[3], 3, 2, iters);
   return 0;
 }

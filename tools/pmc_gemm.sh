@@ -13,7 +13,7 @@ pi=0
 for P in "${PROBS[@]}"; do
   si=0
   for S in "${SETS[@]}"; do
-    timeout 120 rocprofv3 --pmc $S --kernel-trace --kernel-include-regex "gemm" --output-format csv -d $OUT/p${pi}_s${si} -o r -- python $REPO/tools/bench_one.py $P 3 > $OUT/p${pi}_s${si}.log 2>&1 || echo "FAILED set $si for $P: $(tail -2 $OUT/p${pi}_s${si}.log | head -1 | cut -c1-200)"
+    timeout 120 rocprofv3 --pmc $S --kernel-trace --kernel-include-regex "gemm" --output-format csv -d $OUT/p${pi}_s${si} -o r -- python $REPO/tools/probes/bench_one.py $P 3 > $OUT/p${pi}_s${si}.log 2>&1 || echo "FAILED set $si for $P: $(tail -2 $OUT/p${pi}_s${si}.log | head -1 | cut -c1-200)"
     si=$((si+1))
   done
   grep "us/launch" $OUT/p${pi}_s0.log

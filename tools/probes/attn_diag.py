@@ -2,7 +2,7 @@
 """DIAG build only (DBIR_DIAG=1 sh diffbir_amd/csrc/build.sh): per-wave s_memtime anatomy of the attention tile loop."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from diffbir_amd import ops
 DEV = torch.device("cuda:0")

@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """Self-attention kernel A/B (DBIR_OPT_ATTN_VARIANT): 2 = default (FOLD softmax), 6 = the pre-round-4 softmax, 4 / 5 =
-its register-budget variants.  Interleaved, min of HIP-event timings.  python tools/attn_tile_ab.py [variants...]"""
+its register-budget variants.  Interleaved, min of HIP-event timings.  python tools/probes/attn_tile_ab.py [variants...]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from diffbir_amd import native, ops  # noqa: E402
 

@@ -1,6 +1,6 @@
 """GPU check of the first-use autotune (diffbir_amd/autotune.py): an image shape / batch the shipped table does not hold
 (768x640, batch 3) — pass 1 tunes every missed key on first use, pass 2 runs from the cache; then the same shape with
-DBIR_AUTOTUNE disabled (nearest-M fallback) for comparison.  python tools/autotune_miss_check.py"""
+DBIR_AUTOTUNE disabled (nearest-M fallback) for comparison.  python tools/probes/autotune_miss_check.py"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["DBIR_AUTOTUNE_CACHE"] = "/tmp/dbir_autotune_check"
 import bench  # noqa: E402

@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """One GEMM problem, one tile code, N launches (for rocprofv3 --pmc runs and A/B timing).
-Usage: python tools/bench_one.py conv B H W Cin Cout tile [iters]   |   lin M N K tile [iters]"""
+Usage: python tools/probes/bench_one.py conv B H W Cin Cout tile [iters]   |   lin M N K tile [iters]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["DBIR_TUNING"] = "0"
 from diffbir_amd import ops  # noqa: E402

@@ -2,13 +2,13 @@
 """Ablation timing of the halo-patch conv kernel (tile 50) on the MI355X: full kernel vs. no epilogue (60) / no MFMAs
 (61) / no steady-state staging (62) / no fragment reads (63), against the de-phased generic kernel (37), for several
 K depths and grid sizes; fits  t(block) = a + b * K_tiles  to separate prologue + epilogue from the K loop.
-Usage: python tools/halo_ablate.py"""
+Usage: python tools/probes/halo_ablate.py"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["DBIR_TUNING"] = "0"
 from diffbir_amd import ops  # noqa: E402

@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """A/B of the halo-patch convolution tiles on the UNet's stride-1 3x3 shapes (batch 16 = the CFG evaluation of 8 images):
-interleaved repetitions, min of HIP-event timings per launch.  python tools/halo_tile_ab.py [tiles...]"""
+interleaved repetitions, min of HIP-event timings per launch.  python tools/probes/halo_tile_ab.py [tiles...]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["DBIR_TUNING"] = "0"
 from diffbir_amd import ops  # noqa: E402

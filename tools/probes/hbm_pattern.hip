@@ -1,7 +1,7 @@
 // Diagnostic (not part of the product): how fast can 256 CUs move a [65536 x 320] f16 activation matrix (42 MB in, 42 MB
 // out) with (1) linear streaming, (2) the GEMM K-tile pattern — 128-row panels fetched as ten 64-byte column slices, three
 // slices in flight (what gemm_pers.hip / gemm_glds.hip do), (3) whole 80 KB row panels fetched contiguously up front.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/hbm_pattern.hip -o gpurun_out/hbm_pattern   (tools/r2_call11.sh)
+// Build: hipcc --offload-arch=gfx950 -O3 tools/probes/hbm_pattern.hip -o gpurun_out/hbm_pattern   (tools/r2_call11.sh)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 

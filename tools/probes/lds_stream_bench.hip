@@ -2,7 +2,7 @@
 // (the fetch-path ceiling of the fused transformer kernels, csrc/xformer.hip: one 512-thread workgroup per CU copies
 // 20.5 KB tiles into a 3-slot LDS ring with counted vmcnt + one barrier per tile, optionally issuing the MFMAs of a
 // real tile (10 per wave) between barriers.)
-//   hipcc --offload-arch=gfx950 -O3 tools/lds_stream_bench.hip -o gpurun_out/lsb && gpurun_out/lsb
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/lds_stream_bench.hip -o gpurun_out/lsb && gpurun_out/lsb
 // Prints GB/s per CU and in aggregate for stream sizes that sit in L2 (3.4 MB), in the Infinity Cache (13 / 54 MB) and
 // in HBM (860 MB), with all workgroups reading the same tile at (nearly) the same time or each starting at its own offset.
 #include <hip/hip_runtime.h>

@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """A/B of GEMM tile variants on the UNet's transformer linears and the non-halo convolutions at batch 16 (the CFG evaluation
 of 8 images): the shipped table's choice (tile 0 -> tuning_gfx950.json) against the tiles given (default: the producer /
-consumer tiles 90 - 92).  Interleaved repetitions, min of HIP-event timings.  python tools/linear_tile_ab.py [tiles...]"""
+consumer tiles 90 - 92).  Interleaved repetitions, min of HIP-event timings.  python tools/probes/linear_tile_ab.py [tiles...]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("DBIR_AUTOTUNE", "0")
 from diffbir_amd import ops  # noqa: E402

@@ -9,7 +9,7 @@
 //   3  n-outer snake    a0b0 a1b0 a1b1 a0b1 a0b2 a1b2 ...         exactly ONE operand changes per MFMA (10 changes)
 //   4  all different    10 A and 10 B registers                   20 changes
 //   5  all the same     a0 b0 ten times                           0 changes (random data, nothing toggles on the inputs)
-//   hipcc --offload-arch=gfx950 -O3 tools/mfma_order.hip -o gpurun_out/mfma_order && gpurun_out/mfma_order
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_order.hip -o gpurun_out/mfma_order && gpurun_out/mfma_order
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>

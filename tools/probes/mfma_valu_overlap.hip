@@ -2,7 +2,7 @@
 // instruction streams) and across the waves resident on it?  (The flash-attention tile loop, csrc/attention.hip, spends
 // per 64-key tile and wave 16 MFMAs = 512 matrix cycles, 33 v_exp_f32 and ~115 other VALU instructions, and runs at
 // ~1650 cycles per wave-tile of SIMD time = the SUM of the three, profiles/r2_attention_anatomy.txt.)
-//   hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_overlap.hip -o gpurun_out/mvo && gpurun_out/mvo
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_valu_overlap.hip -o gpurun_out/mvo && gpurun_out/mvo
 // Every variant runs `iters` rounds of a "tile": NM MFMAs (32x32x16 f16, 4 independent accumulator chains), NE v_exp_f32
 // and NF v_fma_f32 (8 independent chains each).  Reported: SIMD cycles per tile-round (wall time x 2.4 GHz / rounds,
 // divided by nothing: waves per SIMD are stated per line).

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """A/B of the fine-phase 256x320 kernel (tile 80, gemm_8p.hip) against the tuned incumbents on the UNet's GEMM shapes of a
 batch-16 evaluation (the CFG evaluation of 8 images): interleaved repetitions in one process, min and median of HIP-event
-timings per launch, random operands.   python tools/p8_ab.py [--lin] [--quick]"""
+timings per launch, random operands.   python tools/probes/p8_ab.py [--lin] [--quick]"""
 import os
 import statistics
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["DBIR_AUTOTUNE"] = "0"
 from diffbir_amd import ops  # noqa: E402

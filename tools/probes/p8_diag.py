@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """(needs a `DBIR_DIAG=1 sh diffbir_amd/csrc/build.sh` library)  Anatomy of the fine-phase kernel (tile 80) on one convolution: per-section s_memtime accumulators (DBIR_P8_VAR=32/34)
 and compile-time ablations (2 no setprio, 4 no MFMA, 8 no staging, 16 no fragment reads, 64 lgkmcnt before the barrier).
-Each variant needs its own process (the variant is read once): python tools/p8_diag.py <var> [B H W Cin Cout]"""
+Each variant needs its own process (the variant is read once): python tools/probes/p8_diag.py <var> [B H W Cin Cout]"""
 import os
 import sys
 
@@ -10,7 +10,7 @@ os.environ["DBIR_P8_VAR"] = var
 os.environ["DBIR_AUTOTUNE"] = "0"
 import torch  # noqa: E402
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from diffbir_amd import ops  # noqa: E402
 
