@@ -137,7 +137,8 @@ def tune(d, out: torch.Tensor, apply_tile_code) -> Optional[int]:
     """Time the candidates of this launch on its real operands; returns the winning code (0 = C heuristic) or None when
     the launch must not be re-run.  The caller launches once more with the returned code (a valid output is left behind)."""
     global _dirty
-    if not ENABLED or torch.cuda.is_current_stream_capturing():
+    from . import plan
+    if not ENABLED or torch.cuda.is_current_stream_capturing() or plan.recording():
         return None
     if d.R and d.R == d.C:
         return None

@@ -321,6 +321,26 @@ extern "C" int dbir_nchw_to_nhwc(int dtype, const float* src0, int C0, const flo
   return DBIR_OK;
 }
 
+// 16-byte row copies between strided 16-bit matrices
+__global__ void copy_rows_kernel(const uint4* __restrict__ src, long long lds8, uint4* __restrict__ dst, long long ldd8,
+                                 long long M, int C8) {
+  GRID_STRIDE(i, M * C8) {
+    const long long m = i / C8;
+    const int c = (int)(i - m * C8);
+    dst[m * ldd8 + c] = src[m * lds8 + c];
+  }
+}
+
+extern "C" int dbir_copy_rows(const void* src, long long lds, void* dst, long long ldd, long long M, int C, void* stream) {
+  DBIR_CHECK_ARG(src && dst && M > 0 && C > 0 && C % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && lds >= C && ldd >= C &&
+                     (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+                 "dbir_copy_rows: need C, lds, ldd multiples of 8 and 16-byte aligned pointers");
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(M * (C / 8))), dim3(TPB), 0, STREAM, reinterpret_cast<const uint4*>(src),
+                     lds / 8, reinterpret_cast<uint4*>(dst), ldd / 8, M, C / 8);
+  DBIR_CHECK_LAUNCH("dbir_copy_rows");
+  return DBIR_OK;
+}
+
 extern "C" int dbir_nhwc_to_nchw(int dtype, const void* src, int src_f32, long long ld, float* dst, int C, int B,
                                  int H, int W, float scale, const float* shift, void* stream) {
   DBIR_CHECK_ARG(src && dst && C > 0 && ld >= C, "dbir_nhwc_to_nchw: bad args");

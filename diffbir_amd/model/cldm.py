@@ -11,6 +11,7 @@ from typing import Dict, List, Set, Tuple
 
 import torch
 
+from .. import plan
 from .clip import FrozenOpenCLIPEmbedder
 from .unet import ControlledUnetModel, ControlNet
 from .vae import AutoencoderKL
@@ -21,6 +22,12 @@ T = torch.Tensor
 # skip-connection injections (zero conv + skip add, 12 GEMMs) issued on the ControlNet's stream beside the UNet's middle
 # block instead of inside the decoder (DBIR_INJECT_SIDE=0: A/B)
 INJECT_ON_SIDE_STREAM = os.environ.get("DBIR_INJECT_SIDE", "1") != "0"
+# Deliberate skew between the two encoders (round 5): the UNet encoder (main stream) starts when the ControlNet (side stream)
+# has issued its encoder block DBIR_ENC_SKEW (counted after the shared CFG prefix; -1 = no wait, the streams start together
+# up to the host's issue order).  Why it can matter: the two encoders run the SAME shapes; started together, both are at the
+# 64x64 level (chip-filling, power-limited kernels) and later both at the 16x16 / 8x8 levels (64 - 320 tiles, half-empty
+# chip) at the same time; skewed, one stream's small kernels run beside the other's large ones.  A/B: profiles/r5_enc_skew_ab.txt
+ENC_SKEW = int(os.environ.get("DBIR_ENC_SKEW", "-1"))
 
 
 class ControlLDM:
@@ -50,6 +57,11 @@ class ControlLDM:
         g = os.environ.get("DBIR_GRAPH", "auto")
         self.use_graph = None if g == "auto" else g == "1"
         self.graph_auto_rows = 2 * 64 * 64
+        # engine option (round 5): the same idea as the HIP graph with the engine's OWN executor — the evaluation is recorded
+        # once into a `dbir_plan` (diffbir_amd/plan.py, csrc/plan.hip) and replayed from C with ONE host call per evaluation
+        # (`dbir_cldm_forward`, the module-level entry point of SURVEY.md 8b).  DBIR_PLAN=1: use plans wherever `use_graph`
+        # would use graphs (and for every evaluation when DBIR_GRAPH=1 as well); 0 (default): graphs / eager as before.
+        self.use_plan = os.environ.get("DBIR_PLAN", "0") == "1"
         self._graphs: "OrderedDict[tuple, _EvalGraph]" = OrderedDict()
         self._graph_pool = None
         self.max_graphs = 6
@@ -136,10 +148,11 @@ class ControlLDM:
                c_txt._version,
                tuple(float(s) for s in self.control_scales), str(self.unet._dtype), bool(self.overlap_streams),
                self.unet._gen, self.controlnet._gen)
+        key = key + (bool(self.use_plan),)
         g = self._graphs.get(key)
         if g is None:
             try:
-                g = _EvalGraph(self, x_noisy, t, c_txt, c_img, cond.get("cfg_pair"))
+                g = (_EvalPlan if self.use_plan else _EvalGraph)(self, x_noisy, t, c_txt, c_img, cond.get("cfg_pair"))
             except Exception as e:  # capture not possible here: keep launching the same kernels eagerly
                 warnings.warn(f"diffbir_amd: HIP graph capture of the network evaluation failed ({e!r}); "
                               "continuing with eager launches")
@@ -184,11 +197,13 @@ class ControlLDM:
         side = self._side_stream.get(x_noisy.device)
         if side is None:
             side = self._side_stream[x_noisy.device] = torch.cuda.Stream(device=x_noisy.device)
-        side.wait_stream(main)                      # inputs produced on the main stream are ready
+        plan.wait_stream(side, main)                # inputs produced on the main stream are ready
+        cn._skew_at = ENC_SKEW
         with torch.cuda.stream(side):
             feats = cn.features(x_noisy, c_img, t, c_txt, pair=pair, t_host=th)
-            done = torch.cuda.Event()
-            done.record(side)
+            done = plan.record_event(side)
+        if getattr(cn, "_skew_event", None) is not None:   # the UNet encoder starts once the ControlNet has reached block ENC_SKEW
+            plan.wait_event(main, cn._skew_event)
         for c in feats:                             # allocated on `side`, consumed (and later freed) on `main`
             c.record_stream(main)
         return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, control_ready=done, pair=pair, t_host=th,
@@ -203,11 +218,10 @@ class ControlLDM:
         side = self._side_stream.get(x_noisy.device)
         if side is None:
             side = self._side_stream[x_noisy.device] = torch.cuda.Stream(device=x_noisy.device)
-        side.wait_stream(main)
+        plan.wait_stream(side, main)
         with torch.cuda.stream(side):
             control = self.controlnet(x_noisy, c_img, t, c_txt, scales=self.control_scales, pair=pair)
-            done = torch.cuda.Event()
-            done.record(side)
+            done = plan.record_event(side)
         for c in control:
             c.record_stream(main)
         return self.unet(x_noisy, t, c_txt, control, only_mid_control=False, control_ready=done, pair=pair)
@@ -247,3 +261,41 @@ class _EvalGraph:
             self.c_img.copy_(c_img)
         self.graph.replay()
         return self.out.clone()  # the static output buffer is overwritten by the next replay
+
+
+class _EvalPlan:
+    """One network evaluation recorded into a native `dbir_plan` (csrc/plan.hip) and replayed through `dbir_cldm_forward`:
+    same launches on the same operands in the same per-stream order as the eager pass, issued from C.  The activations live
+    in a private PyTorch memory pool owned by this object (diffbir_amd/plan.py explains why their reuse pattern is safe to
+    replay).  Interface of `_EvalGraph`."""
+
+    def __init__(self, cldm: ControlLDM, x: T, t: T, c_txt: T, c_img: T, pair=None):
+        dev = x.device
+        self.c_txt = c_txt
+        self.pool = torch.cuda.MemPool()
+        with torch.cuda.use_mem_pool(self.pool, device=dev):
+            self.x = x.detach().float().contiguous().clone()
+            self.t = t.detach().to(torch.float32).contiguous().clone()
+            self.c_img = c_img.detach().float().contiguous().clone()
+        cond = dict(c_txt=c_txt, c_img=self.c_img, cfg_pair=pair)
+        # warm-up outside the recording: packs weights, fills the context K/V cache, sizes split-K workspaces, lets the
+        # first-use autotuner settle every problem key (it re-runs launches: never inside a recording)
+        cldm._forward_eager(self.x, self.t, cond)
+        torch.cuda.synchronize(dev)
+        self.ctx_kv = (cldm.unet.context_kv(c_txt), cldm.controlnet.context_kv(c_txt))
+        self._keep = []
+        with torch.cuda.use_mem_pool(self.pool, device=dev):
+            with plan.Recorder(torch.cuda.current_stream(dev)) as rec:
+                self.out = cldm._forward_eager(self.x, self.t, cond)
+        torch.cuda.synchronize(dev)
+        self.plan = rec.build()
+        self.eps = torch.empty_like(self.out)
+        for slot, buf in enumerate((self.x, self.t, self.c_img, self.out)):
+            self.plan.bind(slot, buf)
+        self.calls, self.n_streams, self.n_events = self.plan.calls, self.plan.n_streams, self.plan.n_events
+
+    def run(self, x: T, t: T, c_img: T) -> T:
+        xs = x.detach().float().contiguous()
+        ts = t.detach().to(torch.float32).contiguous()
+        cs = c_img.detach().float().contiguous()
+        return self.plan.cldm_forward(xs, ts, cs, torch.empty_like(self.out))

@@ -27,7 +27,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from .. import ops
+from .. import ops, plan
 from .base import NativeModule
 from .specs import UNetPlan, controlnet_spec, unet_spec
 
@@ -54,6 +54,9 @@ SKIP_ON_SIDE = os.environ.get("DBIR_SKIP_SIDE", "0") == "1"
 # 2-byte scattered stores), the slowest launch per FLOP of an evaluation.  Padded to 64 zero channels (K = 576: 12 GFLOP of
 # zeros, a 4 MB input instead of 0.5 MB) it is an ordinary halo-patch / direct-to-LDS convolution.  DBIR_CONV_IN_PAD=8: A/B.
 CONV_IN_PAD = int(os.environ.get("DBIR_CONV_IN_PAD", "64"))
+# time-embedding rows cached per host-known timestep (DBIR_TEMB_CACHE=0: recompute them in every evaluation, as a HIP-graph /
+# plan replay must — A/B for what the four small GEMMs at the head of each network's stream cost)
+TEMB_CACHE = os.environ.get("DBIR_TEMB_CACHE", "1") != "0"
 
 
 def _unique_of_pairs(t: T, pair: Tuple[int, int]) -> T:
@@ -66,6 +69,14 @@ def _expand_pairs(t: T, pair: Tuple[int, int]) -> T:
     """Inverse of `_unique_of_pairs`: [G*bs, ...] -> [G*2*bs, ...] with both halves of every group equal (one copy)."""
     G, bs = pair
     rest = t.shape[1:]
+    if t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous() and t.shape[-1] % 8 == 0:
+        # engine kernel (dbir_copy_rows) instead of a torch copy: the whole evaluation stays on C-ABI calls (recordable)
+        out = torch.empty((G * 2 * bs,) + tuple(rest), dtype=t.dtype, device=t.device)
+        src, dst = t.reshape(G, bs, -1, rest[-1]), out.reshape(G, 2, bs, -1, rest[-1])
+        for g in range(G):
+            for h in range(2):
+                ops.copy_rows(src[g], dst[g, h])
+        return out
     # .contiguous(): materialise — for G == bs == 1 the reshape of the expanded view would stay a stride-0 view
     return t.reshape(G, 1, bs, *rest).expand(G, 2, bs, *rest).contiguous().reshape(G * 2 * bs, *rest)
 
@@ -183,7 +194,8 @@ class _DiffusionNet(NativeModule):
         t_host: the caller's promise that every element of `t` equals this host scalar (the samplers know their schedule):
         the rows are then computed once per (timestep, batch) and reused by every later step / pipeline pass."""
         key = None
-        if t_host is not None and not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if t_host is not None and TEMB_CACHE and not (t.is_cuda and torch.cuda.is_current_stream_capturing()) \
+                and not plan.recording():
             key = (float(t_host), t.shape[0], str(self._dtype), str(t.device), self._gen)
             hit = self._temb_cache.get(key)
             if hit is not None:
@@ -208,19 +220,17 @@ class _DiffusionNet(NativeModule):
         if r.skip is not None and side is not None and x.is_cuda:
             main = torch.cuda.current_stream()
             skip = torch.empty(x.shape[:-1] + (r.skip.n_out,), dtype=x.dtype, device=x.device)   # owned by the main stream
-            ready = torch.cuda.Event()
-            ready.record(main)                      # x (the concat buffer) is complete on this stream
+            ready = plan.record_event(main)         # x (the concat buffer) is complete on this stream
             with torch.cuda.stream(side):
-                side.wait_event(ready)
+                plan.wait_event(side, ready)
                 ops.linear(x, r.skip, out=skip)
-                skip_ev = torch.cuda.Event()
-                skip_ev.record(side)
+                skip_ev = plan.record_event(side)
         h = ops.groupnorm(x, r.gn1[0], r.gn1[1], 1e-5, True, stats=x_stats)
         h, st = ops.conv3x3(h, r.conv1, rowvec=emb_all[:, r.emb_slice[0]:r.emb_slice[1]], stats=want) if want else \
             (ops.conv3x3(h, r.conv1, rowvec=emb_all[:, r.emb_slice[0]:r.emb_slice[1]]), None)
         h = ops.groupnorm(h, r.gn2[0], r.gn2[1], 1e-5, True, stats=st)
         if skip_ev is not None:
-            torch.cuda.current_stream().wait_event(skip_ev)
+            plan.wait_event(torch.cuda.current_stream(), skip_ev)
         elif skip is None:
             skip = x if r.skip is None else ops.linear(x, r.skip)
         if want:
@@ -329,7 +339,11 @@ class _DiffusionNet(NativeModule):
             h, st = self._attn(enc[1][2], h, ctx_kv, pair=pair, x_stats=st)
             hs.append(h)
             enc = enc[2:]
-        for blk in enc:
+        self._skew_event = None
+        skew_at = getattr(self, "_skew_at", -1)
+        for bi, blk in enumerate(enc):
+            if bi == skew_at and h.is_cuda:   # ControlLDM: the UNet encoder on the other stream starts when this point is reached
+                self._skew_event = plan.record_event(torch.cuda.current_stream())
             if blk[0] == "conv_in":
                 h, st = ops.conv3x3(h, blk[1]), None
             elif blk[0] == "res":
@@ -389,7 +403,7 @@ class ControlledUnetModel(_DiffusionNet):
         h = ops.nchw_to_nhwc(x if pair is None else _unique_of_pairs(x, pair), None, CONV_IN_PAD, self._dtype)
         hs, h = self._encode(h, emb_all, ctx_kv, pair)
         if control_ready is not None:
-            torch.cuda.current_stream().wait_event(control_ready)
+            plan.wait_event(torch.cuda.current_stream(), control_ready)
         control = list(control) if control is not None else None
         if control_feats is not None:
             assert control is None
@@ -422,11 +436,10 @@ class ControlledUnetModel(_DiffusionNet):
         pre = None   # skip injections issued ahead on the control stream: per decoder block (column sums | None, event)
         if control_feats is not None and control_stream is not None and not only_mid_control and h.is_cuda:
             main = torch.cuda.current_stream()
-            enc_done = torch.cuda.Event()
-            enc_done.record(main)                   # hs (this encoder's skips) are complete
+            enc_done = plan.record_event(main)      # hs (this encoder's skips) are complete
             pre = []
             with torch.cuda.stream(control_stream):
-                control_stream.wait_event(enc_done)
+                plan.wait_event(control_stream, enc_done)
                 for i, (res, att, up, b) in enumerate(self.dec):
                     f, z, sc = cf[-2 - i]           # cf[-1] is the middle block's feature, then the skips last to first
                     right = bufs[i][..., b["cin"] - b["skip"]:]
@@ -435,8 +448,7 @@ class ControlledUnetModel(_DiffusionNet):
                         st = ops.linear(f, z, out_scale=sc, residual=hs[-1 - i], out=right, stats=True)[1]
                     else:
                         ops.linear(f, z, out_scale=sc, residual=hs[-1 - i], out=right)
-                    ev = torch.cuda.Event()
-                    ev.record(control_stream)       # decoder block i waits for ITS injection only: the rest run beside it
+                    ev = plan.record_event(control_stream)   # decoder block i waits for ITS injection only: the rest run beside it
                     pre.append((st, ev))
             for st, _ev in pre:                     # allocated on the control stream, consumed (and freed) on this one
                 if st is not None:
@@ -457,7 +469,7 @@ class ControlledUnetModel(_DiffusionNet):
             skip = hs.pop()
             right = buf[..., b["cin"] - b["skip"]:]
             if pre is not None:
-                torch.cuda.current_stream().wait_event(pre[i][1])
+                plan.wait_event(torch.cuda.current_stream(), pre[i][1])
                 done, rst = True, pre[i][0]
             else:
                 done, rst = (False, None) if only_mid_control else add_control(skip, right)

@@ -76,6 +76,14 @@ SIGNATURES = {
     "dbir_wavelet_blur": [_P, _P, _I, _I, _I, _I, _P],
     "dbir_colorfix": [_P, _P, _P, _P, _LL, _P],
     "dbir_f32_nchw_to_u8_nhwc": [_P, _P, _I, _I, _I, _P],
+    "dbir_copy_rows": [_P, _LL, _P, _LL, _LL, _I, _P],
+    "dbir_plan_fn_index": [c_char_p],
+    "dbir_plan_create": [_P, _P, _I, _P, _LL, _I, _I],
+    "dbir_plan_bind": [_P, _I, _P, _LL],
+    "dbir_plan_run": [_P, _P],
+    "dbir_plan_num_ops": [_P],
+    "dbir_plan_destroy": [_P],
+    "dbir_cldm_forward": [_P, _P, _P, _P, _P, _P],
     "dbir_abi_version": [],
     "dbir_set_option": [_I, _I],
 }

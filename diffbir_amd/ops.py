@@ -677,6 +677,15 @@ def add_scaled(a: T, b: T, s: float, out: Optional[T] = None) -> T:
     return out
 
 
+def copy_rows(src: T, dst: T) -> T:
+    """dst[..., :C] = src[..., :C] for 16-bit channels-last tensors of equal shape (row strides may differ)."""
+    _gpu(src, dst)
+    assert src.shape == dst.shape and src.dtype == dst.dtype and src.element_size() == 2
+    native.check(native.lib().dbir_copy_rows(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), _rows(src), src.shape[-1],
+                                             _stream()), "dbir_copy_rows")
+    return dst
+
+
 def space_to_depth2(x: T) -> T:
     """[B, 2h, 2w, C] 16-bit NHWC (row stride may exceed C) -> [B, h, w, 4C], channel = (ky*2 + kx)*C + c."""
     _gpu(x)

@@ -39,7 +39,8 @@ const char* dbir_last_error(void);
  * dbir_xf_geometry, dbir_groupnorm_affine, dbir_groupnorm_from_partials; tiles 80 - 89 retired, 90 - 92 added.
  * 4 since round 4: dbir_gemm_desc.stats holds [sum, M2] per (row tile, column) instead of [sum, sum of squares] (and
  * dbir_groupnorm_from_partials reads that), split-K launches emit them; tile 80 = the fine-phase 256x320 kernel.
- * 5 since round 5: dbir_gemm_desc.upsample == 2 (parity-collapsed upsample convolution), dbir_groupnorm_apply_partials. */
+ * 5 since round 5: dbir_gemm_desc.upsample == 2 (parity-collapsed upsample convolution), dbir_groupnorm_apply_partials,
+ * dbir_copy_rows, dbir_plan_* / dbir_cldm_forward (module-level entry point: a recorded network evaluation replayed from C). */
 int dbir_abi_version(void);
 /* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 2 (default) = LDS-resident
  * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape, 4 / 5 =
@@ -343,6 +344,44 @@ int dbir_colorfix(const float* content, const float* content_low, const float* s
                   long long n, void* stream);
 /* dst_u8[b,y,x,c] = (uint8) clamp(src[b,c,y,x] * 255, 0, 255)  (pipeline.py:312-320; truncating cast). */
 int dbir_f32_nchw_to_u8_nhwc(const float* src, unsigned char* dst, int B, int H, int W, void* stream);
+
+/* dbir_copy_rows: dst[m, :C] (ldd) = src[m, :C] (lds) for 16-bit rows, C % 8 == 0, 16-byte aligned (the duplication of the
+ * distinct samples of a classifier-free-guidance batch, model/unet.py `_expand_pairs`; keeps the whole network evaluation on
+ * engine kernels so that it can be recorded into a dbir_plan). */
+int dbir_copy_rows(const void* src, long long lds, void* dst, long long ldd, long long M, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Module-level entry point (`dbir_cldm_forward`): ONE host call per network evaluation.
+ *
+ * A dbir_plan is the recorded launch sequence of one ControlLDM evaluation (reference cldm.py:160-172: ControlNet + UNet,
+ * ~600 calls of the operator entry points above on two streams) for fixed shapes, text context and control scales.  The host
+ * side records it once while it runs the evaluation eagerly (diffbir_amd/plan.py: every argument of every call, which of
+ * the plan's streams it went to, and the event record / wait pairs that order the two streams); dbir_plan_run replays it from
+ * C — the same kernels on the same operands in the same per-stream order, no Python, no ctypes marshalling.  All device
+ * memory the recorded calls touch is owned by the caller (a private PyTorch pool kept alive with the plan); the plan owns its
+ * side streams, events and a copy of the call list.
+ *   ops      : n_ops records.  fn >= 0: index of an operator entry point (dbir_plan_fn_index(name)); its arguments except the
+ *              trailing stream in a[] (ints / long longs in .i, floats in .f, device pointers in .p); a dbir_gemm_desc
+ *              argument is passed as a byte offset (.i) into `blob`.  fn == DBIR_PLAN_EVENT_RECORD: record event a[0].i on
+ *              the op's stream; fn == DBIR_PLAN_STREAM_WAIT: the op's stream waits for event a[0].i.
+ *   stream   : per op, a slot: 0 = the stream handed to dbir_plan_run, 1 .. n_streams - 1 = streams the plan creates.
+ * dbir_plan_bind names the evaluation's static input / output buffers (slot 0 x, 1 t, 2 c_img, 3 eps output: device
+ * pointers inside the recorded memory + byte sizes); dbir_cldm_forward copies the caller's x / t / c_img into them (skipped
+ * when the pointers already match), replays the plan and copies the result to `eps` — everything enqueued on `stream`. */
+typedef union dbir_arg { long long i; double f; void* p; } dbir_arg;
+#define DBIR_PLAN_MAX_ARGS 24
+#define DBIR_PLAN_EVENT_RECORD (-1)
+#define DBIR_PLAN_STREAM_WAIT (-2)
+typedef struct dbir_plan_op { int fn, stream, nargs, reserved; dbir_arg a[DBIR_PLAN_MAX_ARGS]; } dbir_plan_op;
+typedef struct dbir_plan dbir_plan;
+int dbir_plan_fn_index(const char* name);   /* -1: not a recordable entry point */
+int dbir_plan_create(dbir_plan** out, const dbir_plan_op* ops, int n_ops, const void* blob, long long blob_bytes,
+                     int n_streams, int n_events);
+int dbir_plan_bind(dbir_plan* plan, int slot, void* device_ptr, long long bytes);
+int dbir_plan_run(dbir_plan* plan, void* stream);
+int dbir_plan_num_ops(const dbir_plan* plan);
+int dbir_plan_destroy(dbir_plan* plan);
+int dbir_cldm_forward(dbir_plan* plan, const float* x, const float* t, const float* c_img, float* eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -205,6 +205,54 @@ def test_brownian_tree_default_path_draws_on_the_device_generator():
     assert cases.psnr_u8(outs[0], outs[1]) > 60.0   # same tree, same noise (the kernels' own run-to-run rounding aside)
 
 
+@pytest.mark.parametrize("pair", [False, True])
+def test_plan_replay_is_bit_identical_to_eager(pair):
+    """The module-level C entry point (include/dbir.h dbir_cldm_forward): one network evaluation recorded into a dbir_plan
+    and replayed from C — ControlNet + UNet on two streams, ~hundreds of operator calls — must reproduce the eager pass BIT
+    FOR BIT (same kernels, same operands, same per-stream order), for new inputs and repeatedly (no stale pointers, no
+    cross-stream race in the replayed memory-reuse pattern), with and without the shared CFG prefix."""
+    from diffbir_amd.model import cldm as cldm_mod
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    cldm.use_graph = False
+    B = 2
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    c_txt = mk(2 * B, 77, cldm.unet.cfg["context_dim"])
+    xs = [mk(B, 4, 64, 64).repeat(2, 1, 1, 1) if pair else mk(2 * B, 4, 64, 64) for _ in range(3)]
+    cis = [mk(B, 4, 64, 64).repeat(2, 1, 1, 1) if pair else mk(2 * B, 4, 64, 64) for _ in range(3)]
+    ts = [torch.full((2 * B,), float(v), device=dev) for v in (999.0, 500.0, 20.0)]
+    kw = dict(cfg_pair=(1, B)) if pair else {}
+    eager = [cldm._forward_eager(x, t, dict(c_txt=c_txt, c_img=ci, **kw)).clone() for x, t, ci in zip(xs, ts, cis)]
+    ev = cldm_mod._EvalPlan(cldm, xs[0], ts[0], c_txt, cis[0], (1, B) if pair else None)
+    assert ev.calls > 100 and ev.n_streams == 2 and ev.n_events >= 2, (ev.calls, ev.n_streams, ev.n_events)
+    for rep in range(3):
+        for i in (0, 1, 2, 1):
+            out = ev.run(xs[i], ts[i], cis[i])
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager[i]), f"replay {rep} of input {i}: max diff {(out - eager[i]).abs().max().item():.3e}"
+    REPORT[f"plan_replay_pair{int(pair)}"] = dict(calls=ev.calls, ops=ev.plan.n_ops, events=ev.n_events)
+
+
+def test_pipeline_through_plans_vs_reference_golden(golden_dir, monkeypatch):
+    """The whole pipeline with every network evaluation replayed from a dbir_plan (ControlLDM.use_plan): same golden, same bar."""
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    cldm.use_graph, cldm.use_plan = True, True
+    from diffbir_amd.model.cldm import _EvalPlan
+    name, dcfg, lqspec, steps, sampler, seed, kw = CASES[0]
+    ref = np.load(os.path.join(golden_dir, "tiny_pipeline.npz"))[name]
+    out = run_pipe(pipe, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+    assert any(isinstance(g, _EvalPlan) for g in cldm._graphs.values()), "no evaluation went through a plan"
+    psnr = cases.psnr_u8(out, ref)
+    REPORT["tiny_pipeline_through_plans"] = psnr
+    assert out.shape == ref.shape and psnr >= 45.0, psnr
+    eager_pipe, ecldm, _ = build_engine("tiny", dcfg, dev, torch.float16)
+    ecldm.use_graph = False
+    base = run_pipe(eager_pipe, cases.make_lq(*lqspec), steps, sampler, seed, **kw)
+    assert np.array_equal(out, base), f"plan-replayed pipeline differs from the eager one: {cases.psnr_u8(out, base):.1f} dB"
+
+
 def test_full_pipeline_50_steps_vs_reference_golden(golden_dir):
     """BASELINE config C1/C2 semantics at batch 1: 512x512, 50 spaced steps, CFG 4.0, v2.1 — PSNR >= 45 dB (fp16)
     against the unmodified reference's CPU fp32 output."""

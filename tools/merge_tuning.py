@@ -14,9 +14,14 @@ def main():
     cur = json.load(open(path))
     new = json.load(open(sys.argv[1]))
     dry = "--dry" in sys.argv
+    # --exclude 90,91,92: never adopt these tiles (the producer / consumer tiles win timed alone and lose in the two-stream
+    # evaluation, profiles/r3_pc_tiles_ab.txt: diffbir_amd/autotune.py does not offer them either)
+    excl = set()
+    if "--exclude" in sys.argv:
+        excl = {int(x) % 100 for x in sys.argv[sys.argv.index("--exclude") + 1].split(",") if x}
     n = 0
     for k, v in sorted(new["tiles"].items()):
-        us = {t: round(u, 1) for t, u in v["us"].items() if u}
+        us = {t: round(u, 1) for t, u in v["us"].items() if u and int(t) % 100 not in excl}
         if not us:
             continue
         ent = cur["tiles"].setdefault(k, dict(tile=0, us={}))
