@@ -63,6 +63,20 @@ CONFIGS = {
 }
 
 
+# parity of each configuration at its benchmarked shape (uint8 output, PSNR; goldens under tests/golden/)
+PARITY = {
+    "c2": "fp16, bar 45 dB (north_star): 57.1 - 57.3 dB per image on batch 8 x 50 steps against the unmodified reference "
+          "(CPU fp32, full_c2_spaced50_b8.npz)",
+    "c3": "fp16, bar 45 dB: 56.8 dB per image on batch 4 x 20 DPM-Solver++(2M) steps against the fp32 oracle on the GPU "
+          "(full_c3_dpm20_b4.npz; that oracle reproduces the reference's C2 / C4 goldens to 86 / 84 dB, max 1 LSB)",
+    "c4": "fp16, bar 45 dB: 57.2 dB on 2048x2048, 49 tiles x 50 steps against the fp32 oracle on the GPU "
+          "(full_c4_tiled2048_spaced50.npz); 56.4 dB on the 10-step golden of the unmodified reference",
+    "c5": "bf16, bar max(34 dB, the reference's OWN bf16-vs-fp32 PSNR - 1.5 dB = 38.9 dB) (north_star states 45 dB for fp16 only): "
+          "45.5 dB on one 4096x4096 image, 225 tiles x 50 steps, against the fp32 oracle on the GPU "
+          "(full_c5_tiled4096_spaced50.npz)",
+}
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,7 +103,7 @@ def parse(argv=None):
                          "1-GPU run of the default configuration (the driver's BENCH line), see --no-pmc")
     ap.add_argument("--no-pmc", action="store_true",
                     help="never run the PMC passes: roofline.traffic then comes from the committed pass of this batch "
-                         "(profiles/r4_pmc_traffic_b<batch>.json) and traffic_source says so")
+                         "(profiles/r5_pmc_traffic_b<batch>.json, else r4 / r3) and traffic_source says so")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the multi-GPU code path on however many ranks there are — with ONE rank: RCCL communicator "
                          "init, bucketed weight broadcast, one all-reduce per tiled evaluation, gather of the outputs on a "
@@ -247,9 +261,10 @@ def measure_roofline(cldm, device, batch, pmc=False):
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
     if out["traffic"] is None:
-        pmc_file = os.path.join(ROOT, "profiles", f"r4_pmc_traffic_b{batch}.json")
-        if not os.path.exists(pmc_file):
-            pmc_file = os.path.join(ROOT, "profiles", f"r3_pmc_traffic_b{batch}.json")
+        pmc_file = os.path.join(ROOT, "profiles", f"r5_pmc_traffic_b{batch}.json")
+        for older in ("r4", "r3"):
+            if not os.path.exists(pmc_file):
+                pmc_file = os.path.join(ROOT, "profiles", f"{older}_pmc_traffic_b{batch}.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 tr = json.load(f)
@@ -507,12 +522,10 @@ def main():
         # prefix the engine executes ~2 % fewer (the roofline record below counts executed FLOPs)
         "mfma_frac_end_to_end": value * fpi / (world * MFMA_PEAK),
         "vs_baseline_note": "BASELINE.json `published` is empty: the reference publishes no throughput numbers",
-        # which parity bar this configuration's dtype is held to (tests/test_pipeline_gpu.py)
-        "parity_bar": ("fp16: PSNR >= 45 dB vs the unmodified reference (CPU fp32) on the uint8 output (north_star); measured "
-                       "56.4 - 57.3 dB on the full-size goldens of this configuration family" if dtype == torch.float16 else
-                       "bf16: >= max(34 dB, the reference's OWN bf16-vs-fp32 PSNR - 1.5 dB) (north_star states 45 dB for fp16 only; "
-                       "bf16 has 3 mantissa bits less = 18 dB); measured 41.2 dB against the reference's 40.4 dB on the "
-                       "full-size tiled golden"),
+        # which parity bar this configuration is held to and what the engine measured on the golden of ITS OWN benchmarked
+        # shape (tests/test_pipeline_gpu.py; profiles/r5_pipeline_parity_report.json)
+        "parity_bar": PARITY[args.config] if args.dtype == CONFIGS[args.config]["dtype"] else
+                      "non-default dtype for this configuration: see tests/test_pipeline_gpu.py for the bf16 / fp16 bars",
     }
     if multi and "rccl" in extra:
         extra["rccl"]["calls"] = dict(parallel.calls)   # collectives issued by diffbir_amd.parallel in this process

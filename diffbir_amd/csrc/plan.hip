@@ -5,6 +5,9 @@
 // UNet's.  dbir_plan_run walks that list: same kernels, same operands, same per-stream order — one host call per evaluation.
 // Nothing here launches a kernel of its own; the operator entry points do (plan_dispatch.inc is generated from the binding's
 // signature table by tools/gen_plan_dispatch.py).
+#include <stdlib.h>
+#include <time.h>
+
 #include <vector>
 
 #include "common.h"
@@ -94,12 +97,28 @@ extern "C" int dbir_plan_bind(dbir_plan* p, int slot, void* device_ptr, long lon
   return DBIR_OK;
 }
 
+// DIAGNOSTIC (env DBIR_PLAN_PACE_NS, default 0): busy-wait this many nanoseconds between two recorded calls — emulates the
+// ~15 - 30 us a Python / ctypes launch takes, to separate "what is launched" from "how fast it is enqueued" when a replay is
+// compared with eager launches (profiles/r5_graph_plan_ab.txt)
+static long long plan_pace_ns() {
+  static const long long v = getenv("DBIR_PLAN_PACE_NS") ? atoll(getenv("DBIR_PLAN_PACE_NS")) : 0;
+  return v;
+}
+
 extern "C" int dbir_plan_run(dbir_plan* p, void* stream) {
   DBIR_CHECK_ARG(p, "dbir_plan_run: null plan");
   hipStream_t main = reinterpret_cast<hipStream_t>(stream);
   const char* blob = p->blob.data();
   const size_t n = p->ops.size();
+  const long long pace = plan_pace_ns();
   for (size_t i = 0; i < n; ++i) {
+    if (pace > 0) {
+      timespec t0, t1;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      do {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+      } while ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) < pace);
+    }
     const dbir_plan_op& o = p->ops[i];
     hipStream_t s = o.stream == 0 ? main : p->streams[o.stream];
     if (o.fn == DBIR_PLAN_EVENT_RECORD) {

@@ -380,7 +380,7 @@ class ControlledUnetModel(_DiffusionNet):
 
     def forward(self, x: T, timesteps: T, context: T, control: Optional[List[T]] = None,
                 only_mid_control: bool = False, control_ready=None, pair: Pair = None, control_feats=None,
-                t_host: Optional[float] = None, control_stream=None, **_) -> T:
+                t_host: Optional[float] = None, control_stream=None, emb_all: Optional[T] = None, **_) -> T:
         """x: f32 NCHW [B,4,h,w]; control: list of 13 NHWC 16-bit tensors (already scaled) or None -> f32 NCHW.
         control_ready: optional torch.cuda.Event recorded by the stream that produces `control` (ControlLDM runs the
         ControlNet concurrently with this encoder); waited for right before the first control tensor is read.
@@ -397,7 +397,8 @@ class ControlledUnetModel(_DiffusionNet):
         self._ensure_packed()
         self._skip_side = None
         ctx_kv = self.context_kv(context)
-        emb_all = self._time_emb(timesteps, t_host)
+        if emb_all is None:   # (a replayed evaluation gets the rows of its timestep from the caller: model/cldm.py)
+            emb_all = self._time_emb(timesteps, t_host)
         x = x.float().contiguous()
         pair = pair if self._pair_ok(pair, x.shape[0]) else None
         h = ops.nchw_to_nhwc(x if pair is None else _unique_of_pairs(x, pair), None, CONV_IN_PAD, self._dtype)
@@ -518,12 +519,13 @@ class ControlNet(_DiffusionNet):
         return [ops.linear(f, z, out_scale=float(s)) for f, z, s in zip(feats, self.zero, scales)]
 
     def features(self, x: T, hint: T, timesteps: T, context: T, pair: Pair = None,
-                 t_host: Optional[float] = None) -> List[T]:
+                 t_host: Optional[float] = None, emb_all: Optional[T] = None) -> List[T]:
         """The 13 feature maps the zero convs are applied to (12 encoder outputs + middle block), NHWC 16-bit.  ControlLDM
         hands them to ControlledUnetModel.forward(control_feats=...) so the zero convs run fused with the skip additions."""
         self._ensure_packed()
         ctx_kv = self.context_kv(context)
-        emb_all = self._time_emb(timesteps, t_host)
+        if emb_all is None:
+            emb_all = self._time_emb(timesteps, t_host)
         x, hint = x.float().contiguous(), hint.float().contiguous()
         pair = pair if self._pair_ok(pair, x.shape[0]) else None
         if pair is not None:
