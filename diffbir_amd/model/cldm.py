@@ -4,6 +4,8 @@ Keeps the reference surface: ``forward(x_noisy, t, cond)``, 
 ``vae_encode``, ``vae_decode``, ``cast_dtype``, ``load_pretrained_sd``, ``load_controlnet_from_ckpt``,
 ``control_scales``, ``eval()``, ``to()``; samplers may re-bind ``model.forward`` (tiling).
 """
+import contextlib
+import gc
 import os
 import warnings
 from collections import OrderedDict
@@ -28,6 +30,8 @@ INJECT_ON_SIDE_STREAM = os.environ.get("DBIR_INJECT_SIDE", "1") != "0"
 # 64x64 level (chip-filling, power-limited kernels) and later both at the 16x16 / 8x8 levels (64 - 320 tiles, half-empty
 # chip) at the same time; skewed, one stream's small kernels run beside the other's large ones.  A/B: profiles/r5_enc_skew_ab.txt
 ENC_SKEW = int(os.environ.get("DBIR_ENC_SKEW", "-1"))
+# (HIP stream priorities were tried and removed: no effect under eager launches — the two streams hardly ever co-run,
+# profiles/r5_eager_vs_plan_kernel_stats.txt — and -18 % on a replay's side stream: profiles/r5_stream_priority_ab.txt)
 
 
 class ControlLDM:
@@ -54,14 +58,21 @@ class ControlLDM:
         # replay wins (2.06 -> 2.28 img/s).  use_graph: True / False, or None = decide per call: graphs when the
         # evaluation holds at most `graph_auto_rows` latent pixels (samples x h x w) = one 512x512 image under CFG.
         # DBIR_GRAPH=0 / 1 / auto (default).
+        # Round 5: (i) a replay used to be REBUILT for every pipeline pass (its key held the prompt tensor's address: two extra
+        # evaluations per 50 steps = the "-2 ... -3 % at batch 8" of every earlier graph A/B); with the text context in
+        # persistent buffer sets (model/unet.py context_kv) a replay survives a new prompt tensor, and at batch 8 plan replay
+        # measures +0.6 ... +1.2 %, graph replay +0.4 % over eager launches, +14 % at batch 1 (profiles/r5_replay_reuse_ab.txt);
+        # (ii) the replayer is the engine's own (`use_plan`, below).  `auto` therefore replays every evaluation of up to
+        # `graph_auto_rows` latent pixels (64 samples of a 64x64 latent: the benchmark's 16-sample evaluation and the tiled
+        # scheduler's 32-sample chunks included); larger ones launch eagerly.
         g = os.environ.get("DBIR_GRAPH", "auto")
         self.use_graph = None if g == "auto" else g == "1"
-        self.graph_auto_rows = 2 * 64 * 64
+        self.graph_auto_rows = 64 * 64 * 64
         # engine option (round 5): the same idea as the HIP graph with the engine's OWN executor — the evaluation is recorded
         # once into a `dbir_plan` (diffbir_amd/plan.py, csrc/plan.hip) and replayed from C with ONE host call per evaluation
-        # (`dbir_cldm_forward`, the module-level entry point of SURVEY.md 8b).  DBIR_PLAN=1: use plans wherever `use_graph`
-        # would use graphs (and for every evaluation when DBIR_GRAPH=1 as well); 0 (default): graphs / eager as before.
-        self.use_plan = os.environ.get("DBIR_PLAN", "0") == "1"
+        # (`dbir_cldm_forward`, the module-level entry point of SURVEY.md 8b).  DBIR_PLAN=1 (default since the end of round 5):
+        # replays go through plans; 0: through HIP graphs (`torch.cuda.CUDAGraph`), as in rounds 2 - 4.
+        self.use_plan = os.environ.get("DBIR_PLAN", "1") == "1"
         self._graphs: "OrderedDict[tuple, _EvalGraph]" = OrderedDict()
         self._graph_pool = None
         self.max_graphs = 6
@@ -139,13 +150,16 @@ class ControlLDM:
         return self._forward_eager(x_noisy, t, cond)
 
     def _forward_graphed(self, x_noisy: T, t: T, cond: Dict[str, T]) -> T:
-        """Replay (or capture) the HIP graph of this evaluation.  Static inputs: x, t, c_img (copied in); the text
-        context is part of the key (its cross-attention K / V^T are cached device tensors the graph reads)."""
+        """Replay (or capture) the HIP graph / plan of this evaluation.  Static inputs: x, t, c_img (copied in), the time-embedding
+        rows (`_ReplayEmb`) and — through the persistent buffer sets — the cross-attention K / V^T of the text context."""
         c_txt, c_img = cond["c_txt"], cond["c_img"]
         self.unet._ensure_packed()
         self.controlnet._ensure_packed()
-        key = (tuple(x_noisy.shape), str(x_noisy.device), cond.get("cfg_pair"), c_txt.data_ptr(), tuple(c_txt.shape),
-               c_txt._version,
+        # the text context enters through the networks' persistent K / V^T buffer sets (model/unet.py context_kv): a new prompt
+        # tensor of the same shape refreshes a set in place (here, on the current stream, in front of the replay), so the key
+        # holds the SET's identity, not the prompt tensor's — a replay survives the next pipeline pass instead of being rebuilt
+        kvu, kvc = self.unet.context_kv(c_txt), self.controlnet.context_kv(c_txt)
+        key = (tuple(x_noisy.shape), str(x_noisy.device), cond.get("cfg_pair"), id(kvu), id(kvc), tuple(c_txt.shape),
                tuple(float(s) for s in self.control_scales), str(self.unet._dtype), bool(self.overlap_streams),
                self.unet._gen, self.controlnet._gen)
         key = key + (bool(self.use_plan),)
@@ -205,8 +219,9 @@ class ControlLDM:
             done = plan.record_event(side)
         if getattr(cn, "_skew_event", None) is not None:   # the UNet encoder starts once the ControlNet has reached block ENC_SKEW
             plan.wait_event(main, cn._skew_event)
-        for c in feats:                             # allocated on `side`, consumed (and later freed) on `main`
-            c.record_stream(main)
+        if not plan.recording():                    # (a recording's allocations live in the plan's private pool: no hand-over)
+            for c in feats:                         # allocated on `side`, consumed (and later freed) on `main`
+                c.record_stream(main)
         return self.unet(x_noisy, t, c_txt, None, only_mid_control=False, control_ready=done, pair=pair, t_host=th, emb_all=eu,
                          control_feats=(feats, cn.zero, self.control_scales),
                          control_stream=side if INJECT_ON_SIDE_STREAM else None)
@@ -229,6 +244,18 @@ class ControlLDM:
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """Cyclic garbage collection off inside the block (see _EvalPlan.__init__)."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class _ReplayEmb:
@@ -293,8 +320,13 @@ class _EvalPlan:
     def __init__(self, cldm: ControlLDM, x: T, t: T, c_txt: T, c_img: T, pair=None):
         dev = x.device
         self.c_txt = c_txt
+        # A cyclic-GC pass that destroys an OLDER plan's MemPool while this thread allocates into a pool aborts the process
+        # inside PyTorch's caching allocator (round 5, full GPU suite: "Fatal Python error: Aborted" in a GC pass during the
+        # recording below; tools/probes/plan_lifetime_probe.py destroys 24 pools between recordings without trouble).  So:
+        # collect garbage NOW, and keep the collector off while a pool context is open.
+        gc.collect()
         self.pool = torch.cuda.MemPool()
-        with torch.cuda.use_mem_pool(self.pool, device=dev):
+        with _no_gc(), torch.cuda.use_mem_pool(self.pool, device=dev):
             self.x = x.detach().float().contiguous().clone()
             self.t = t.detach().to(torch.float32).contiguous().clone()
             self.c_img = c_img.detach().float().contiguous().clone()
@@ -308,7 +340,8 @@ class _EvalPlan:
         torch.cuda.synchronize(dev)
         self.ctx_kv = (cldm.unet.context_kv(c_txt), cldm.controlnet.context_kv(c_txt))
         self._keep = []
-        with torch.cuda.use_mem_pool(self.pool, device=dev):
+        gc.collect()
+        with _no_gc(), torch.cuda.use_mem_pool(self.pool, device=dev):
             with plan.Recorder(torch.cuda.current_stream(dev)) as rec:
                 self.out = cldm._forward_eager(self.x, self.t, cond)
         torch.cuda.synchronize(dev)
@@ -317,6 +350,17 @@ class _EvalPlan:
         for slot, buf in enumerate((self.x, self.t, self.c_img, self.out)):
             self.plan.bind(slot, buf)
         self.calls, self.n_streams, self.n_events = self.plan.calls, self.plan.n_streams, self.plan.n_events
+        # Self-check before the plan is trusted: a replay on OTHER inputs must equal the eager evaluation of those inputs bit
+        # for bit.  A device operation that is not a C-ABI call (a stray torch copy inside the evaluation) is invisible to the
+        # recorder — the replay would silently reuse that buffer's contents from the recording pass (this is how the tiled
+        # scheduler's strided gather was found: 5.7 dB).  Two evaluations, once per plan.
+        xv, cv = (self.x * 0.5 + 0.25).contiguous(), (self.c_img * 0.5 - 0.125).contiguous()
+        want = cldm._forward_eager(xv, self.t, dict(cond, c_img=cv)).clone()
+        got = self.run(xv, self.t, cv)
+        torch.cuda.synchronize(dev)
+        if not torch.equal(got, want):
+            raise RuntimeError(f"dbir_plan self-check failed: replay differs from the eager evaluation (max abs "
+                               f"{(got - want).abs().max().item():.3e}) — some device operation of the evaluation is not recorded")
 
     def run(self, x: T, t: T, c_img: T, t_host=None) -> T:
         xs = x.detach().float().contiguous()

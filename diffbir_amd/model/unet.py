@@ -54,6 +54,9 @@ SKIP_ON_SIDE = os.environ.get("DBIR_SKIP_SIDE", "0") == "1"
 # 2-byte scattered stores), the slowest launch per FLOP of an evaluation.  Padded to 64 zero channels (K = 576: 12 GFLOP of
 # zeros, a 4 MB input instead of 0.5 MB) it is an ordinary halo-patch / direct-to-LDS convolution.  DBIR_CONV_IN_PAD=8: A/B.
 CONV_IN_PAD = int(os.environ.get("DBIR_CONV_IN_PAD", "64"))
+# persistent cross-attention K / V^T buffer sets per context shape (`_DiffusionNet.context_kv`): 2 = a cond / uncond pair that
+# alternates keeps both resident; a third prompt tensor of the same shape refreshes the older set in place
+CTX_SETS = int(os.environ.get("DBIR_CTX_SETS", "2"))
 # time-embedding rows cached per host-known timestep (DBIR_TEMB_CACHE=0: recompute them in every evaluation, as a HIP-graph /
 # plan replay must — A/B for what the four small GEMMs at the head of each network's stream cost)
 TEMB_CACHE = os.environ.get("DBIR_TEMB_CACHE", "1") != "0"
@@ -62,6 +65,18 @@ TEMB_CACHE = os.environ.get("DBIR_TEMB_CACHE", "1") != "0"
 def _unique_of_pairs(t: T, pair: Tuple[int, int]) -> T:
     """[G*2*bs, ...] laid out as G groups of (bs uncond, bs cond) with identical halves -> [G*bs, ...] (first halves)."""
     G, bs = pair
+    if G == 1:   # the first half of a contiguous tensor is a view
+        return t.reshape(G, 2, bs, *t.shape[1:])[:, 0].reshape(G * bs, *t.shape[1:]).contiguous()
+    per = 1
+    for d in t.shape[1:]:
+        per *= d
+    if t.is_cuda and t.is_contiguous() and (bs * per * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0:
+        # G > 1 (the tiled scheduler's chunks): a strided gather — through the engine's row-copy kernel, NOT a torch copy: every
+        # device operation of an evaluation must be a C-ABI call, or a recorded plan (diffbir_amd/plan.py) silently replays
+        # without it (found by the tiled golden: 5.7 dB)
+        out = torch.empty((G * bs,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        ops.copy_rows2d(t.reshape(G, 2 * bs * per)[:, : bs * per], out.reshape(G, bs * per))
+        return out
     return t.reshape(G, 2, bs, *t.shape[1:])[:, 0].reshape(G * bs, *t.shape[1:]).contiguous()
 
 
@@ -238,31 +253,53 @@ class _DiffusionNet(NativeModule):
         return ops.conv3x3(h, r.conv2, residual=skip, out=out), None
 
     def context_kv(self, c_txt: T) -> list:
-        """Cross-attention K and V^T of every transformer layer for a text context [B, 77, ctx_dim] (cached:
-        c_txt is constant over all sampling steps)."""
+        """Cross-attention K and V^T of every transformer layer for a text context [B, 77, ctx_dim] (c_txt is constant over
+        all sampling steps: computed once per prompt tensor).
+
+        The results live in PERSISTENT buffer sets — up to CTX_SETS per (shape, dtype, device) — that a new prompt tensor of
+        the same shape refreshes IN PLACE (least recently used set first): a recorded / captured evaluation (model/cldm.py
+        `_EvalPlan`, `_EvalGraph`) points at a set's storage, so it stays valid when the next pipeline pass brings a new c_txt
+        instead of being re-recorded — the two extra evaluations per pass that cost replays 4 % (profiles/r5_eager_vs_plan_
+        kernel_stats.txt: each pass of 50 steps built a new plan).  Returns the set's list (identity = the set)."""
         self._ensure_packed()
-        key = (c_txt.data_ptr(), tuple(c_txt.shape), c_txt._version, str(self._dtype))
-        hit = self._ctx_cache.get(key)
-        if hit is not None:
-            return hit
+        content = (c_txt.data_ptr(), tuple(c_txt.shape), c_txt._version, self._gen)
+        skey = (tuple(c_txt.shape), str(self._dtype), str(c_txt.device), self._gen)
+        sets = self._ctx_cache.setdefault(skey, [])
+        for i, st in enumerate(sets):
+            if st["content"] == content:
+                sets.append(sets.pop(i))
+                return st["kv"]
         B, L, D = c_txt.shape
         c = c_txt.to(self._dtype).contiguous().reshape(B * L, D)
         Lp = (L + 7) // 8 * 8
-        kv = []
-        for a in self._attn_layers:
-            k = ops.linear(c, a.k2).reshape(B, L, a.ch)
-            vt = torch.zeros((B, a.ch, Lp), dtype=self._dtype, device=c.device)
-            ops.linear_t(c, a.v2, L, vt)
-            if a.xf is not None and L <= 96:  # fragment-ordered copy for the fused tail kernel
-                kv.append((k, vt) + tuple(ops.pack_context_frags(k, vt, L, a.heads)))
-            else:
-                kv.append((k, vt))
-        if len(self._ctx_cache) > 64:
-            self._ctx_cache.clear()
-        self._ctx_cache[key] = kv
-        # keep c_txt alive so its data_ptr cannot be recycled while the entry exists
-        kv.append(c_txt)
-        return kv
+        if len(sets) < CTX_SETS:
+            kv = []
+            for a in self._attn_layers:
+                k = torch.empty((B, L, a.ch), dtype=self._dtype, device=c.device)
+                vt = torch.zeros((B, a.ch, Lp), dtype=self._dtype, device=c.device)   # pad columns stay zero for ever
+                ops.linear(c, a.k2, out=k.reshape(B * L, a.ch))
+                ops.linear_t(c, a.v2, L, vt)
+                if a.xf is not None and L <= 96:  # fragment-ordered copy for the fused tail kernel
+                    kv.append((k, vt) + tuple(ops.pack_context_frags(k, vt, L, a.heads)))
+                else:
+                    kv.append((k, vt))
+            st = dict(kv=kv)
+            if len(self._ctx_cache) > 16:   # shapes come and go (tiled scheduler chunk sizes): bound the table
+                self._ctx_cache.pop(next(iter(self._ctx_cache)))
+                sets = self._ctx_cache.setdefault(skey, [])
+        else:
+            st = sets.pop(0)
+            for a, ent in zip(self._attn_layers, st["kv"]):
+                k, vt = ent[0], ent[1]
+                ops.linear(c, a.k2, out=k.reshape(B * L, a.ch))
+                ops.linear_t(c, a.v2, L, vt)
+                if len(ent) == 4:
+                    kf, vf = ops.pack_context_frags(k, vt, L, a.heads)
+                    ent[2].copy_(kf)
+                    ent[3].copy_(vf)
+        st["content"], st["keep"] = content, c_txt   # keep c_txt alive: its data_ptr must not be recycled while it is the key
+        sets.append(st)
+        return st["kv"]
 
     def _attn(self, a: _Attn, x: T, ctx_kv: list, out: Optional[T] = None, pair: Pair = None, x_stats=None):
         """pair: x holds the distinct samples of a CFG batch; the result is the full batch (see module docstring).
@@ -452,7 +489,7 @@ class ControlledUnetModel(_DiffusionNet):
                     ev = plan.record_event(control_stream)   # decoder block i waits for ITS injection only: the rest run beside it
                     pre.append((st, ev))
             for st, _ev in pre:                     # allocated on the control stream, consumed (and freed) on this one
-                if st is not None:
+                if st is not None and not plan.recording():
                     st.buf.record_stream(main)
             mid_feat = cf.pop()
             del cf[:]

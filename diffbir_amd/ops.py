@@ -686,6 +686,19 @@ def copy_rows(src: T, dst: T) -> T:
     return dst
 
 
+def copy_rows2d(src: T, dst: T) -> T:
+    """dst[m, :] = src[m, :] for 2-D tensors of ANY element type whose rows are contiguous (row strides may differ); a row must
+    be a multiple of 16 bytes.  (dbir_copy_rows moves 16-byte chunks: the row is described in 2-byte units.)"""
+    _gpu(src, dst)
+    assert src.dim() == 2 and src.shape == dst.shape and src.dtype == dst.dtype and src.stride(1) == 1 and dst.stride(1) == 1
+    es = src.element_size()
+    rb, sb, db = src.shape[1] * es, src.stride(0) * es, dst.stride(0) * es
+    assert rb % 16 == 0 and sb % 16 == 0 and db % 16 == 0, "copy_rows2d: rows and row strides must be multiples of 16 bytes"
+    native.check(native.lib().dbir_copy_rows(src.data_ptr(), sb // 2, dst.data_ptr(), db // 2, src.shape[0], rb // 2, _stream()),
+                 "dbir_copy_rows")
+    return dst
+
+
 def space_to_depth2(x: T) -> T:
     """[B, 2h, 2w, C] 16-bit NHWC (row stride may exceed C) -> [B, h, w, 4C], channel = (ky*2 + kx)*C + c."""
     _gpu(x)

@@ -234,6 +234,33 @@ def test_plan_replay_is_bit_identical_to_eager(pair):
     REPORT[f"plan_replay_pair{int(pair)}"] = dict(calls=ev.calls, ops=ev.plan.n_ops, events=ev.n_events)
 
 
+@pytest.mark.parametrize("mode", ["eager", "graph", "plan"])
+def test_new_prompt_tensors_refresh_the_context_buffers_in_place(mode):
+    """The cross-attention K / V^T of the text context live in persistent buffer sets (2 per shape) that a new prompt tensor
+    refreshes IN PLACE (model/unet.py context_kv): five different prompt tensors of one shape, revisited in a mixed order, must
+    give the results of a fresh engine each time — eagerly, and through HIP-graph / plan replays, which must be REUSED (at most
+    one per buffer set) instead of being rebuilt for every new prompt tensor."""
+    dev = _dev()
+    pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    ref_pipe, ref, _ = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
+    ref.use_graph = False
+    cldm.use_graph, cldm.use_plan = mode != "eager", mode == "plan"
+    B, D = 2, cldm.unet.cfg["context_dim"]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    ctxs = [mk(B, 77, D) for _ in range(5)]
+    x, ci, t = mk(B, 4, 64, 64), mk(B, 4, 64, 64), torch.full((B,), 321.0, device=dev)
+    for i in (0, 1, 2, 0, 3, 4, 1, 1, 2):
+        got = cldm.forward(x, t, dict(c_txt=ctxs[i], c_img=ci))
+        torch.cuda.synchronize()
+        ref.unet._ctx_cache.clear()
+        ref.controlnet._ctx_cache.clear()
+        want = ref._forward_eager(x, t, dict(c_txt=ctxs[i].clone(), c_img=ci))
+        assert torch.equal(got, want), f"{mode}: context {i}: max diff {(got - want).abs().max().item():.3e}"
+    if mode != "eager":
+        assert 1 <= len(cldm._graphs) <= 2, f"{len(cldm._graphs)} replays for 5 prompt tensors of one shape (2 buffer sets)"
+
+
 def test_pipeline_through_plans_vs_reference_golden(golden_dir, monkeypatch):
     """The whole pipeline with every network evaluation replayed from a dbir_plan (ControlLDM.use_plan): same golden, same bar."""
     dev = _dev()
@@ -610,13 +637,15 @@ def test_cleaner_pipelines_vs_reference_golden(golden_dir, name):
 
 
 @torch.no_grad()
-def test_graph_replay_equals_eager():
-    """HIP-graph replay of the network evaluation (automatic for small batches: the host's ~700 launches per evaluation
-    outlast the GPU work) runs the same kernels on the same data as eager launching: bit-identical uint8 results,
-    untiled and tiled, and the automatic policy picks graphs for the single-image evaluation."""
+@pytest.mark.parametrize("use_plan", [False, True], ids=["hip_graph", "dbir_plan"])
+def test_graph_replay_equals_eager(use_plan):
+    """Replay of the network evaluation — HIP graph, or the engine's own recorded plan (the default since round 5) — runs the
+    same kernels on the same data as eager launching: bit-identical uint8 results, untiled and tiled, several samplers, and
+    the automatic policy replays the evaluations of these pipelines."""
     dev = _dev()
     pipe, cldm, swin = build_engine("tiny", "DIFFUSION_V21", dev, torch.float16)
     assert cldm.use_graph is None or isinstance(cldm.use_graph, bool)
+    cldm.use_plan = use_plan
     outs = {}
     for mode in (False, True, None):
         cldm.use_graph = mode

@@ -25,6 +25,7 @@ def main():
     dev = torch.device("cuda:0")
     pipe, cldm, swin = bench.build_engine(dev, torch.float16)
     cldm.overlap_streams = False
+    cldm.use_graph = False   # per-launch instrumentation (HIP events / PMC per kernel): eager launches, never a replay
     B2 = 2 * a.batch
     x = torch.randn(B2, 4, 64, 64, device=dev)
     cond = dict(c_txt=torch.randn(B2, 77, 1024, device=dev), c_img=torch.randn(B2, 4, 64, 64, device=dev))
