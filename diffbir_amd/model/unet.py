@@ -114,6 +114,7 @@ class _DiffusionNet(NativeModule):
         self.plan = UNetPlan(cfg, hint_channels=hint_channels)
         self.dtype = torch.float32  # reference attribute (cast_dtype sets it); engine dtype is self._dtype
         self._ctx_cache: Dict[tuple, list] = {}
+        self._ctx_evicted: Dict[tuple, tuple] = {}   # context shape -> identity of the prompt tensor last overwritten in place
         # time-embedding rows per host-known timestep (hoisted out of the step loop — a timestep recurs
         # in every pipeline pass and is the same for all samples of a batch): (t, rows, dtype, gen) -> emb_all
         self._temb_cache: "OrderedDict[tuple, T]" = OrderedDict()
@@ -202,6 +203,7 @@ class _DiffusionNet(NativeModule):
         self.emb_all = ops.pack_linear(w, b, self._dtype, self._device)
         del self._emb_w, self._emb_b
         self._ctx_cache.clear()
+        self._ctx_evicted.clear()
 
     # ------------------------------------------------------------------ forward pieces
     def _time_emb(self, t: T, t_host: Optional[float] = None) -> T:
@@ -256,8 +258,9 @@ class _DiffusionNet(NativeModule):
         """Cross-attention K and V^T of every transformer layer for a text context [B, 77, ctx_dim] (c_txt is constant over
         all sampling steps: computed once per prompt tensor).
 
-        The results live in PERSISTENT buffer sets — up to CTX_SETS per (shape, dtype, device) — that a new prompt tensor of
-        the same shape refreshes IN PLACE (least recently used set first): a recorded / captured evaluation (model/cldm.py
+        The results live in PERSISTENT buffer sets — one per (shape, dtype, device), a second one (up to CTX_SETS) only for a
+        caller that alternates between two contexts — that a new prompt tensor of the same shape refreshes IN PLACE (least
+        recently used set first): a recorded / captured evaluation (model/cldm.py
         `_EvalPlan`, `_EvalGraph`) points at a set's storage, so it stays valid when the next pipeline pass brings a new c_txt
         instead of being re-recorded — the two extra evaluations per pass that cost replays 4 % (profiles/r5_eager_vs_plan_
         kernel_stats.txt: each pass of 50 steps built a new plan).  Returns the set's list (identity = the set)."""
@@ -272,7 +275,12 @@ class _DiffusionNet(NativeModule):
         B, L, D = c_txt.shape
         c = c_txt.to(self._dtype).contiguous().reshape(B * L, D)
         Lp = (L + 7) // 8 * 8
-        if len(sets) < CTX_SETS:
+        # a further set is only opened when a context that was just overwritten COMES BACK (a caller alternating between two
+        # contexts of one shape, e.g. a sampler doing the reference's two forwards per step): a stream of ever-new prompt
+        # tensors (one per pipeline pass) keeps refreshing ONE set, so the replay recorded against it is reused from the
+        # second pass on
+        ping_pong = self._ctx_evicted.get(skey) == content[:3]
+        if not sets or (len(sets) < CTX_SETS and ping_pong):
             kv = []
             for a in self._attn_layers:
                 k = torch.empty((B, L, a.ch), dtype=self._dtype, device=c.device)
@@ -289,6 +297,7 @@ class _DiffusionNet(NativeModule):
                 sets = self._ctx_cache.setdefault(skey, [])
         else:
             st = sets.pop(0)
+            self._ctx_evicted[skey] = st["content"][:3]
             for a, ent in zip(self._attn_layers, st["kv"]):
                 k, vt = ent[0], ent[1]
                 ops.linear(c, a.k2, out=k.reshape(B * L, a.ch))

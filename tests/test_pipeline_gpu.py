@@ -250,15 +250,17 @@ def test_new_prompt_tensors_refresh_the_context_buffers_in_place(mode):
     mk = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
     ctxs = [mk(B, 77, D) for _ in range(5)]
     x, ci, t = mk(B, 4, 64, 64), mk(B, 4, 64, 64), torch.full((B,), 321.0, device=dev)
-    for i in (0, 1, 2, 0, 3, 4, 1, 1, 2):
+    seq = (0, 1, 2, 0, 3, 4, 1, 1, 2, 3, 2, 3, 2)   # ever-new prompts (one buffer set), then two contexts alternating (a second set)
+    for i in seq:
         got = cldm.forward(x, t, dict(c_txt=ctxs[i], c_img=ci))
         torch.cuda.synchronize()
         ref.unet._ctx_cache.clear()
         ref.controlnet._ctx_cache.clear()
         want = ref._forward_eager(x, t, dict(c_txt=ctxs[i].clone(), c_img=ci))
         assert torch.equal(got, want), f"{mode}: context {i}: max diff {(got - want).abs().max().item():.3e}"
+    assert len(next(iter(cldm.unet._ctx_cache.values()))) == 2, "the alternating pair must have opened the second buffer set"
     if mode != "eager":
-        assert 1 <= len(cldm._graphs) <= 2, f"{len(cldm._graphs)} replays for 5 prompt tensors of one shape (2 buffer sets)"
+        assert len(cldm._graphs) == 2, f"{len(cldm._graphs)} replays for 5 prompt tensors of one shape (one per buffer set)"
 
 
 def test_pipeline_through_plans_vs_reference_golden(golden_dir, monkeypatch):
