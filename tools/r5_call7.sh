@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-5 GPU call 7: does the RATE at which a replay enqueues its launches matter?  (plan replay with a busy-wait between
-# recorded calls: DBIR_PLAN_PACE_NS) + the refreshed tile table against the round-4 table in situ.
+# recorded calls: DBIR_PLAN_PACE_NS) + the refreshed tile table against the round-4 table in situ
+# (before the call: git show 8e4ae0a:diffbir_amd/tuning_gfx950.json > gpurun_tuning_r4.json   — git-ignored scratch copy).
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/r5c7
 mkdir -p $O

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round-5 GPU call 9: HIP stream priority of the ControlNet's stream (eager) / of the plan's side stream (replay).
+# (The two knobs DBIR_SIDE_PRIO / DBIR_PLAN_SIDE_PRIO existed at commit d8ea50b+ only; they measured null / -18 % and were removed:
+#  profiles/r5_stream_priority_ab.txt.  Kept as the record of what was run.)
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/r5c9
 mkdir -p $O
