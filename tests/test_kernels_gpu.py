@@ -1261,6 +1261,29 @@ def test_block2x2_space_depth(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_copy_rows(dtype):
+    """dbir_copy_rows (the engine's own gather / scatter of the CFG pairs, model/unet.py:_unique_of_pairs / _expand_pairs):
+    pure data movement between strided matrices — exact, and nothing outside the destination rows is touched."""
+    from diffbir_amd.native import NativeError
+    x = rnd(2, 5, 7, 160, dtype=dtype)
+    wide = torch.zeros(2, 5, 7, 200, dtype=dtype, device=DEV)
+    ops.copy_rows(x[..., 32:128], wide[..., 104:])                # strided source and destination (channel slices)
+    assert torch.equal(wide[..., 104:], x[..., 32:128]) and float(wide[..., :104].abs().max()) == 0.0
+    big = rnd(3000, 320, dtype=dtype, seed=1)                    # more 16-byte chunks than one pass of the grid covers
+    assert torch.equal(ops.copy_rows(big, torch.empty_like(big)), big)
+    # 2-D form on any element type: the first half of every row group (how the tiled scheduler takes one of each CFG pair)
+    for t in (rnd(4, 72, dtype=torch.float32, seed=2), rnd(6, 2 * 64 * 24, dtype=dtype, seed=3)):
+        n = t.shape[1] // 2
+        out = torch.full((t.shape[0], n), 7, dtype=t.dtype, device=DEV)
+        assert torch.equal(ops.copy_rows2d(t[:, :n], out), t[:, :n])
+        back = torch.zeros_like(t)
+        ops.copy_rows2d(out, back[:, n:])                         # strided destination
+        assert torch.equal(back[:, n:], t[:, :n]) and float(back[:, :n].abs().max()) == 0.0
+    with pytest.raises(NativeError):                              # rows that are not whole 16-byte chunks are refused
+        ops.copy_rows(x[..., :12], wide[..., :12])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_and_elementwise(dtype):
     a, b = rnd(2, 9, 7, 96, dtype=dtype), rnd(2, 9, 7, 160, dtype=dtype, seed=1)
     out1, out2 = torch.zeros(2, 9, 7, 200, dtype=dtype, device=DEV), torch.zeros(2, 9, 7, 200, dtype=dtype, device=DEV)
