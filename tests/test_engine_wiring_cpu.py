@@ -300,3 +300,55 @@ def test_spaced_sampler_does_not_mutate_callers_cond(engine):
     s.sample(_Model(), "cpu", 3, (1, 4, 8, 8), cond, uncond, 4.0, progress=False)
     assert set(cond) == keys_c and set(uncond) == keys_u, "sample() wrote into the caller's condition dicts"
     assert len(seen) == 3 and all(th is not None and th == t for t, th in seen), seen
+
+
+@torch.no_grad()
+def test_context_buffer_sets_bookkeeping(engine):
+    """model/unet.py context_kv: the cross-attention K / V^T of a text context live in persistent buffer sets that recorded /
+    captured evaluations point at.  A stream of new prompt tensors of one shape keeps refreshing ONE set in place (same list,
+    same storage — replays stay valid); a second set is opened only when a context that was just overwritten comes back
+    (two alternating contexts); an in-place edit of the prompt tensor is noticed (version counter); values always equal a
+    fresh computation."""
+    from diffbir_amd.model import unet as unet_mod
+    pipe, cldm, swin = engine
+    net = cldm.unet
+    rs = cases.NoiseStream(21)
+    D = net.cfg["context_dim"]
+    a, b, c = rs((2, 77, D)), rs((2, 77, D)), rs((2, 77, D))
+
+    def fresh(ctx):   # what a network without any cached state computes
+        saved, net._ctx_cache, net._ctx_evicted = (net._ctx_cache, net._ctx_evicted), {}, {}
+        out = [tuple(t.clone() for t in ent) for ent in net.context_kv(ctx)]
+        net._ctx_cache, net._ctx_evicted = saved
+        return out
+
+    def same(kv, ref):
+        return all(torch.equal(x, y) for e, r in zip(kv, ref) for x, y in zip(e, r))
+
+    kva = net.context_kv(a)
+    ptrs = [t.data_ptr() for ent in kva for t in ent]
+    assert net.context_kv(a) is kva                                   # hit: nothing recomputed, same set
+    assert same(kva, fresh(a))
+    # a stream of new prompt tensors: ONE set, refreshed in place
+    kvb = net.context_kv(b)
+    assert kvb is kva and [t.data_ptr() for ent in kvb for t in ent] == ptrs and same(kvb, fresh(b))
+    kvc = net.context_kv(c)
+    assert kvc is kva and same(kvc, fresh(c))
+    skey = next(k for k in net._ctx_cache if k[0] == (2, 77, D))
+    assert len(net._ctx_cache[skey]) == 1
+    # b was overwritten by c and comes back: the caller alternates -> a second set (up to CTX_SETS), both then stay put
+    kvb2 = net.context_kv(b)
+    assert kvb2 is not kva and same(kvb2, fresh(b)) and same(kva, fresh(c))
+    assert len(net._ctx_cache[skey]) == min(2, unet_mod.CTX_SETS)
+    for _ in range(3):
+        assert net.context_kv(c) is kva and net.context_kv(b) is kvb2
+    # an in-place edit of the prompt tensor is a new content (tensor version), refreshed into the least recently used set
+    b.mul_(0.5)
+    kvb3 = net.context_kv(b)
+    assert kvb3 is kva and same(kvb3, fresh(b))                        # (c's set was the least recently used one)
+    # another shape gets its own set; the first shape's sets are untouched
+    d = rs((1, 77, D))
+    kvd = net.context_kv(d)
+    assert kvd is not kva and kvd is not kvb2 and kvd[0][0].shape[0] == 1
+    assert same(kvb2, fresh(b * 2.0))                                  # still the values of b before the edit: not touched
+    assert net.context_kv(b) is kvb3
