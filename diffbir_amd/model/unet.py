@@ -293,7 +293,9 @@ class _DiffusionNet(NativeModule):
                     kv.append((k, vt))
             st = dict(kv=kv)
             if len(self._ctx_cache) > 16:   # shapes come and go (tiled scheduler chunk sizes): bound the table
-                self._ctx_cache.pop(next(iter(self._ctx_cache)))
+                oldest = next(iter(self._ctx_cache))
+                self._ctx_cache.pop(oldest)
+                self._ctx_evicted.pop(oldest, None)
                 sets = self._ctx_cache.setdefault(skey, [])
         else:
             st = sets.pop(0)
