@@ -32,6 +32,9 @@ struct F16 {
   static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
 };
 struct BF16 {
   typedef bf16x8 vec8;
@@ -43,6 +46,9 @@ struct BF16 {
   }
   static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
 

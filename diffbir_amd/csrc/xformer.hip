@@ -894,6 +894,16 @@ int xf_launch_head(int dtype, int grid, hipStream_t s, const XfParams& p) {
 
 void dbir_xf_set_variant(int v) { g_xf_variant = v; }
 
+// second-generation kernels (csrc/xformer2.hip): selected by the LENGTH of the packed weight stream (diffbir_amd/xformer.py packs one
+// format or the other; the two lengths differ for every C)
+extern "C" int dbir_xf2_geometry(int C, int* panel_rows, long long* head_bytes, long long* tail_bytes, int* tail_prm_floats);
+int dbir_xf2_tail_impl(int dtype, const void* attn_out, long long ldo, const void* h, long long ldh, const void* x, long long ldx,
+                       void* out, long long ldout, int M, int L, int C, int pair_bs, const void* wstream, const float* prm,
+                       const void* kfrag, const void* vfrag, int Lk, float scale, int stop_after, void* stream);
+int dbir_xf2_head_impl(int dtype, const void* x, long long ldx, const float* gn_scale_shift, void* h, long long ldh, void* qk,
+                       long long ldqk, void* vt, long long vt_ld, long long vt_bstride, int M, int L, int C, const void* wstream,
+                       const float* prm, void* stream);
+
 extern "C" int dbir_xf_tile_bytes(void) { return TILE_BYTES; }
 extern "C" int dbir_xf_tail_tiles(void) { return XfCfg<320>::TAIL_TILES; }
 extern "C" int dbir_xf_head_tiles(void) { return XfCfg<320>::HEAD_TILES; }
@@ -913,6 +923,9 @@ extern "C" int dbir_xf_tail(int dtype, const void* attn_out, long long ldo, cons
   DBIR_CHECK_ARG(attn_out && h && x && out && wstream && prm && kfrag && vfrag, "dbir_xf_tail: null pointer");
   DBIR_CHECK_ARG(dtype == DBIR_F16 || dtype == DBIR_BF16, "dbir_xf_tail: bad dtype %d", dtype);
   DBIR_CHECK_ARG(C == 320 || C == 640, "dbir_xf_tail: built for C = 320 and 640 (got %d)", C);
+  long long v2_tail_bytes = 0;
+  dbir_xf2_geometry(C, nullptr, nullptr, &v2_tail_bytes, nullptr);
+  const bool v2 = wstream_bytes == v2_tail_bytes;
   const int BM = C == 320 ? XfCfg<320>::BM : XfCfg<640>::BM;
   const int tiles = C == 320 ? XfCfg<320>::TAIL_TILES : XfCfg<640>::TAIL_TILES;
   DBIR_CHECK_ARG(M > 0 && L > 0 && L % BM == 0 && M % L == 0, "dbir_xf_tail: M %d must be whole samples of L %d rows, L %% %d == 0", M, L, BM);
@@ -923,12 +936,15 @@ extern "C" int dbir_xf_tail(int dtype, const void* attn_out, long long ldo, cons
                    reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(wstream) | reinterpret_cast<uintptr_t>(prm) |
                    reinterpret_cast<uintptr_t>(kfrag) | reinterpret_cast<uintptr_t>(vfrag)) & 15) == 0,
                  "dbir_xf_tail: pointers must be 16-byte aligned");
-  DBIR_CHECK_ARG(wstream_bytes >= (long long)tiles * TILE_BYTES, "dbir_xf_tail: weight stream too short");
+  DBIR_CHECK_ARG(v2 || wstream_bytes >= (long long)tiles * TILE_BYTES, "dbir_xf_tail: weight stream too short");
   DBIR_CHECK_ARG(Lk > 0 && Lk <= XLKP, "dbir_xf_tail: context length %d > %d", Lk, XLKP);
   const long long src_rows = pair_bs ? M / 2 : M;
   DBIR_CHECK_ARG(((src_rows - 1) * ldo + C) * 2 < 0x7ffffe00LL && ((src_rows - 1) * ldh + C) * 2 < 0x7ffffe00LL &&
                      ((src_rows - 1) * ldx + C) * 2 < 0x7ffffe00LL && ((long long)(M - 1) * ldout + C) * 2 < 0x7ffffe00LL,
                  "dbir_xf_tail: a tensor is too large for a 2 GB buffer descriptor");
+  if (v2)
+    return dbir_xf2_tail_impl(dtype, attn_out, ldo, h, ldh, x, ldx, out, ldout, M, L, C, pair_bs, wstream, prm, kfrag, vfrag, Lk, scale,
+                              stop_after, stream);
   XfParams p;
   memset(&p, 0, sizeof(p));
   p.o = (const u16*)attn_out; p.ldo = ldo;
@@ -957,6 +973,9 @@ extern "C" int dbir_xf_head(int dtype, const void* x, long long ldx, const float
   DBIR_CHECK_ARG(x && gn_scale_shift && h && qk && vt && wstream && prm, "dbir_xf_head: null pointer");
   DBIR_CHECK_ARG(dtype == DBIR_F16 || dtype == DBIR_BF16, "dbir_xf_head: bad dtype %d", dtype);
   DBIR_CHECK_ARG(C == 320 || C == 640, "dbir_xf_head: built for C = 320 and 640 (got %d)", C);
+  long long v2_head_bytes = 0;
+  dbir_xf2_geometry(C, nullptr, &v2_head_bytes, nullptr, nullptr);
+  const bool v2 = wstream_bytes == v2_head_bytes;
   const int BM = C == 320 ? XfCfg<320>::BM : XfCfg<640>::BM;
   const int tiles = C == 320 ? XfCfg<320>::HEAD_TILES : XfCfg<640>::HEAD_TILES;
   DBIR_CHECK_ARG(M > 0 && L > 0 && L % BM == 0 && M % L == 0, "dbir_xf_head: M %d must be whole samples of L %d rows, L %% %d == 0", M, L, BM);
@@ -967,11 +986,12 @@ extern "C" int dbir_xf_head(int dtype, const void* x, long long ldx, const float
                    reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(wstream) | reinterpret_cast<uintptr_t>(prm) |
                    reinterpret_cast<uintptr_t>(gn_scale_shift)) & 15) == 0,
                  "dbir_xf_head: pointers must be 16-byte aligned");
-  DBIR_CHECK_ARG(wstream_bytes >= (long long)tiles * TILE_BYTES, "dbir_xf_head: weight stream too short");
+  DBIR_CHECK_ARG(v2 || wstream_bytes >= (long long)tiles * TILE_BYTES, "dbir_xf_head: weight stream too short");
   DBIR_CHECK_ARG(((long long)(M - 1) * ldx + C) * 2 < 0x7ffffe00LL && ((long long)(M - 1) * ldh + C) * 2 < 0x7ffffe00LL &&
                      ((long long)(M - 1) * ldqk + 2 * C) * 2 < 0x7ffffe00LL &&
                      ((long long)(M / L - 1) * vt_bstride + (long long)(C - 1) * vt_ld + L) * 2 < 0x7ffffe00LL,
                  "dbir_xf_head: a tensor is too large for a 2 GB buffer descriptor");
+  if (v2) return dbir_xf2_head_impl(dtype, x, ldx, gn_scale_shift, h, ldh, qk, ldqk, vt, vt_ld, vt_bstride, M, L, C, wstream, prm, stream);
   XfParams p;
   memset(&p, 0, sizeof(p));
   p.o = (const u16*)x; p.ldo = ldx;

@@ -27,6 +27,7 @@ column-scaled, the W beta rows are the accumulators' initial values (parameter r
   hidden units = two runs of 8 GEGLU-projection tiles in the C = 320 format (run s = hidden blocks 4c + 2s, 4c + 2s + 1),
   then 8 one-k-step tiles of ff.net.2 columns [128 c, 128 c + 128).)  `geometry(C)` has the numbers.
 """
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -42,6 +43,13 @@ TILE_BYTES = TILE_W + TILE_AUX
 HEAD_TILES, TAIL_TILES = 40, 160            # C = 320
 LK_PAD = 96
 MIN_PANELS_640 = 160   # C = 640: 64-row panels, one per CU — below ~160 panels the per-launch kernels win (idle CUs)
+# Kernel generation the weights are packed for (the C side picks its kernels by the stream length):
+#   2 (default, round 6) = csrc/xformer2.hip — 8 waves x (64 rows x 80 columns) on v_mfma_f32_16x16x32, weights streamed
+#       straight into registers: per column group one flat sequence of 1 KB pieces (16 output columns x 32 k, lane
+#       16 lg + lr = W[16 blk + lr, 32 ks + 8 lg .. + 8]) in consumption order, + a copy of its first 10 pieces (ring wrap);
+#   1 = csrc/xformer.hip (rounds 3 - 5; kept for same-box A/B: DBIR_XF_VERSION=1).
+XF_VERSION = int(os.environ.get("DBIR_XF_VERSION", "2"))
+V2_RING = 10
 
 
 @dataclass(frozen=True)
@@ -87,6 +95,7 @@ class XfBlock:
     tail_prm: T             # f32 [5, C]: to_out1 bias, Wq2 beta2, to_out2 bias, ff.net.2 bias, proj_out bias
     heads: int
     logical: Dict[str, T]   # the unpacked 16-bit weights / f32 vectors (validation tools and the CPU test double)
+    version: int = 1        # kernel generation the streams are packed for
 
 
 def _pieces(w: T) -> T:
@@ -122,10 +131,70 @@ def _finish_stream(tiles: T, aux: Optional[T], device) -> T:
     return out.to(device)
 
 
-def pack_block(w: Dict[str, T], dtype, device) -> XfBlock:
+def _pieces16(w: T) -> T:
+    """[N, K] (N % 16 == 0, K % 32 == 0) -> [N/16, K/32, 64, 8]: lane 16 lg + lr of piece (blk, ks) = W[16 blk + lr, 32 ks + 8 lg ..+8]."""
+    N, K = w.shape
+    return w.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(N // 16, K // 32, 64, 8).contiguous()
+
+
+def _v2_gemm_pieces(w: T, cg: int) -> T:
+    """[C, K] -> the pieces of column group cg (80 output columns) of a GEMM, k-step major: [K/32 * 5, 64, 8]."""
+    p = _pieces16(w)[5 * cg:5 * cg + 5]              # [5, K/32, 64, 8]
+    return p.permute(1, 0, 2, 3).reshape(-1, 64, 8)
+
+
+def _v2_stream(groups, device) -> T:
+    """per column group a list of piece tensors [n, 64, 8] (16 bit) -> uint8 [CG * (pieces + ring)] * 1024 on `device`."""
+    out = []
+    for parts in groups:
+        st = torch.cat(parts)
+        out.append(torch.cat([st, st[:V2_RING]]))
+    body = torch.stack(out).contiguous().view(torch.uint8).reshape(-1)
+    # + one trailing KB (never read): keeps every second-generation stream length distinct from the first generation's
+    return torch.cat([body, torch.zeros(1024, dtype=torch.uint8)]).to(device)
+
+
+def _pack_block_v2(g: Dict[str, T], dtype, device, head_prm: T, tail_prm5: T, q1w, k1w, v1w, q2w, ff1w, ff1b, logical) -> XfBlock:
+    C = g["proj_in.w"].shape[0]
+    CG, KS = C // 80, C // 32
+    CHH = 16 * CG
+    NCH, GK = 4 * C // CHH, CHH // 32
+    h = lambda t: t.to(dtype)  # noqa: E731
+    pi, pq, pk, pv = h(g["proj_in.w"]), h(q1w), h(k1w), h(v1w)
+    o1, q2, o2, po = h(g["out1.w"]), h(q2w), h(g["out2.w"]), h(g["proj_out.w"])
+    p1 = _pieces16(h(ff1w))                           # [8C/16, KS, 64, 8]: values then gates
+    p2 = _pieces16(h(g["ff2.w"]))                     # [C/16, 4C/32, 64, 8]
+    head_groups, tail_groups = [], []
+    b1t = torch.zeros(NCH, CG, 2, 16)
+    for cg in range(CG):
+        head_groups.append([_v2_gemm_pieces(t, cg) for t in (pi, pq, pk, pv)])
+
+        def f1(c):
+            bv = (c * CHH + 16 * cg) // 16
+            bg = (4 * C + c * CHH + 16 * cg) // 16
+            return torch.stack([p1[bv], p1[bg]], dim=1).reshape(-1, 64, 8)      # [KS, 2] -> k-step major
+
+        def f2(c):
+            return p2[5 * cg:5 * cg + 5, c * GK:(c + 1) * GK].permute(1, 0, 2, 3).reshape(-1, 64, 8)
+
+        ff = [f1(0)]
+        for c in range(1, NCH):
+            ff += [f1(c), f2(c - 1)]
+        ff.append(f2(NCH - 1))
+        tail_groups.append([_v2_gemm_pieces(o1, cg), _v2_gemm_pieces(q2, cg), _v2_gemm_pieces(o2, cg)] + ff + [_v2_gemm_pieces(po, cg)])
+        for c in range(NCH):
+            h0 = c * CHH + 16 * cg
+            b1t[c, cg, 0] = ff1b[h0:h0 + 16]
+            b1t[c, cg, 1] = ff1b[4 * C + h0:4 * C + h0 + 16]
+    tail_prm = torch.cat([tail_prm5.reshape(-1).cpu(), b1t.reshape(-1)]).contiguous().to(device)
+    return XfBlock(_v2_stream(head_groups, device), head_prm, _v2_stream(tail_groups, device), tail_prm, C // 64, logical, 2)
+
+
+def pack_block(w: Dict[str, T], dtype, device, version: Optional[int] = None) -> XfBlock:
     """w: the block's tensors by short name (any float dtype / device) —
     proj_in.{w,b}, norm1.{w,b}, q1.w, k1.w, v1.w, out1.{w,b}, norm2.{w,b}, q2.w, out2.{w,b}, norm3.{w,b}, ff1.{w,b},
     ff2.{w,b}, proj_out.{w,b}."""
+    version = XF_VERSION if version is None else version
     g = {k: v.detach().float().cpu().reshape(v.shape[0], -1) if v.dim() > 1 else v.detach().float().cpu() for k, v in w.items()}
     C = g["proj_in.w"].shape[0]
     geo = geometry(C)
@@ -142,6 +211,8 @@ def pack_block(w: Dict[str, T], dtype, device) -> XfBlock:
     if torch.empty(0, dtype=dtype).element_size() != 2:  # f32 test double (CPU wiring tests): no kernel streams
         e = torch.empty((0, TILE_BYTES), dtype=torch.uint8, device=device)
         return XfBlock(e, head_prm, e, tail_prm, C // 64, logical)
+    if version == 2:
+        return _pack_block_v2(g, dtype, device, head_prm, tail_prm, q1w, k1w, v1w, q2w, ff1w, ff1b, logical)
     h = lambda name: g[name].to(dtype)  # noqa: E731  (weights are rounded to the 16-bit compute type once, here)
     head = torch.cat([_tiles_nc(t.to(dtype)) for t in (g["proj_in.w"], q1w, k1w, v1w)])
     w1, b1 = _geglu_interleave(ff1w, ff1b)
@@ -166,7 +237,23 @@ def pack_block(w: Dict[str, T], dtype, device) -> XfBlock:
                    C // 64, logical)
 
 
-def pack_context_frags(k: T, vt: T, Lk: int, heads: int) -> Tuple[T, T]:
+def _pack_context_frags_v2(k: T, vt: T, Lk: int, heads: int) -> Tuple[T, T]:
+    """xformer2.hip (16x16x32 MFMAs): kf [B, heads, 6, 2, 64, 8]: lane 16 lg + lr of (key block kb, d-step ds) =
+    K[16 kb + lr, 64 h + 32 ds + 8 lg ..+8];  vf [B, heads, 4, 3, 64, 8]: lane 16 lg + lr of (d block db, key-step ss) =
+    V^T[64 h + 16 db + lr, keys 32 ss + 4 lg + {0..3}, 32 ss + 16 + 4 lg + {0..3}] — the key order in which the softmax
+    probabilities sit in the S^T accumulators.  Keys >= Lk are zero."""
+    B, _, C = k.shape
+    kp = torch.zeros((B, LK_PAD, C), dtype=k.dtype, device=k.device)
+    kp[:, :Lk] = k[:, :Lk]
+    kf = kp.reshape(B, 6, 16, heads, 2, 4, 8).permute(0, 3, 1, 4, 5, 2, 6).reshape(B, heads, 6, 2, 64, 8).contiguous()
+    vp = torch.zeros((B, C, LK_PAD), dtype=vt.dtype, device=vt.device)
+    vp[:, :, :Lk] = vt[:, :, :Lk]
+    vv = vp.reshape(B, heads, 4, 16, 3, 2, 4, 4)                    # [B, h, db, lr, ss, half, lg, e]
+    vf = vv.permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(B, heads, 4, 3, 64, 8).contiguous()
+    return kf, vf
+
+
+def pack_context_frags(k: T, vt: T, Lk: int, heads: int, version: Optional[int] = None) -> Tuple[T, T]:
     """Text-context K [B, Lk, C] and V^T [B, C, >= Lk] of one block -> MFMA fragment order per (sample, head):
     kf [B, heads, 3, 4, 64, 8]: lane 32 hi + lq of (key block kb, d-step ks) = K[32 kb + lq, 64 h + 16 ks + 8 hi ..+8]
     vf [B, heads, 2, 6, 64, 8]: lane 32 hi + lq of (d block t, key-step s)  = V^T[64 h + 32 t + lq, keys 16 s + 4 hi +
@@ -174,6 +261,8 @@ def pack_context_frags(k: T, vt: T, Lk: int, heads: int) -> Tuple[T, T]:
     Keys >= Lk are zero."""
     B, _, C = k.shape
     assert Lk <= LK_PAD and C == heads * 64
+    if (XF_VERSION if version is None else version) == 2:
+        return _pack_context_frags_v2(k, vt, Lk, heads)
     kp = torch.zeros((B, LK_PAD, C), dtype=k.dtype, device=k.device)
     kp[:, :Lk] = k[:, :Lk]
     kf = kp.reshape(B, 3, 32, heads, 4, 2, 8).permute(0, 3, 1, 4, 5, 2, 6).reshape(B, heads, 3, 4, 64, 8).contiguous()
