@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 if [ -n "$DBIR_DIAG" ]; then FLAGS="$FLAGS -DDBIR_DIAG"; fi
-SRCS="api gemm gemm_glds gemm_halo gemm_pers gemm_8p attention norm elementwise swin clip xformer xformer2 plan"
+SRCS="api gemm gemm_glds gemm_halo gemm_pers gemm_8p gemm_rs attention norm elementwise swin clip xformer xformer2 plan"
 mkdir -p build
 # objects built with a different flag set (e.g. a DBIR_DIAG build) must not be linked into this one
 if [ "$(cat build/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f build/*.o; echo "$FLAGS" > build/.flags; fi

@@ -282,6 +282,9 @@ int dbir_gemm_pers(const dbir_gemm_desc& d, int tile, hipStream_t s);
 bool dbir_gemm_8p_eligible(const dbir_gemm_desc& d);
 int dbir_gemm_8p(const dbir_gemm_desc& d, int Hv, int Wv, int tile, hipStream_t s);
 
+// register-streaming linear kernel (gemm_rs.hip), tiles 93 - 97
+bool dbir_gemm_rs_eligible(const dbir_gemm_desc& d, int tile);
+int dbir_gemm_rs(const dbir_gemm_desc& d, int tile, hipStream_t s);
 // rows per tile for which the launch that just ran emits GroupNorm column sums (dbir_gemm_desc.stats); set by the
 // direct-to-LDS / halo launchers, 0 otherwise
 thread_local int g_dbir_stats_rows = 0;
@@ -335,7 +338,15 @@ static int dbir_gemm_impl(const dbir_gemm_desc* dd, void* stream) {
   if (d.act == DBIR_ACT_GEGLU) DBIR_CHECK_ARG(d.N % 64 == 0, "dbir_gemm: GEGLU needs packed N %% 64 == 0");
   if (d.batch <= 0) d.batch = 1;
   int tile = d.tile;
-  DBIR_CHECK_ARG(tile >= 0 && tile <= 92 && tile != 13 && !(tile >= 74 && tile <= 89 && tile != 80), "dbir_gemm: bad tile %d", tile);
+  DBIR_CHECK_ARG(tile >= 0 && tile <= 97 && tile != 13 && !(tile >= 74 && tile <= 89 && tile != 80), "dbir_gemm: bad tile %d", tile);
+  if (tile >= 93) {
+    DBIR_CHECK_ARG(dbir_gemm_rs_eligible(d, tile),
+                   "dbir_gemm: tile %d (register-streaming linear kernel) needs a dense linear with K %% 64 == 0, M / N multiples of "
+                   "the tile, a 16-bit row-major output, bias / residual epilogue only (no activation, row vector, scale, "
+                   "split-K, batch, transposed or f32 store)", tile);
+    d.stats = nullptr;
+    return dbir_gemm_rs(d, tile, reinterpret_cast<hipStream_t>(stream));
+  }
   if (tile == 80) {
     DBIR_CHECK_ARG(dbir_gemm_8p_eligible(d),
                    "dbir_gemm: tile 80 (fine-phase 256x320 kernel) needs a linear / 3x3 convolution with K / Cin %% 32 == 0, "

@@ -100,7 +100,7 @@ __device__ __forceinline__ void x2_for(F&& fn) {
 // ===============================================================================================================
 // xf2_tail
 // ===============================================================================================================
-template <typename T, int DBG, int CC>  // DBG 1 = intermediate dumps (tests)
+template <typename T, int DBG, int CC>  // DBG 1 = intermediate dumps (tests), 2 = section timing (DBIR_DIAG builds, tools/probes/xf2_anatomy.py)
 __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = X2Cfg<CC>;
@@ -415,6 +415,16 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     }
   };
   const float one4[4] = {1.f, 1.f, 1.f, 1.f};
+  // DEBUG anatomy (DBG == 2): s_memtime per section, summed over this workgroup's panels, written by waves 0 and 4 into `h`
+  unsigned long long ta[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  if (DBG == 2) tprev = __builtin_amdgcn_s_memtime();
+  auto ts = [&](int i) __attribute__((always_inline)) {
+    if constexpr (DBG == 2) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      ta[i] += now - tprev;
+      tprev = now;
+    }
+  };
 
   for (int pi = 0; pi < nmine; ++pi) {
     const int panel = x0 + loc + pi * p.gx;
@@ -448,20 +458,25 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     acc_bias(0);
     acc_add_rows(h_srd, p.ldh, srow0);
     x2barrier();
+    ts(0);
     // ---------------- phase 1: h1 = attn @ Wo1^T + b + h;  X = LayerNorm2(h1) ----------------
     gemm5(smem + (4 * rg) * KS * 1024, X2_IC(KS));
+    ts(1);
     round_to_hres();
     if (DBG == 1 && p.stop_after == 11) { dump_hres(row0); continue; }
     layernorm_to_x();
     acc_bias(1);  // q = LN2(h1) Wq^T: beta2 Wq^T (the folded LayerNorm shift) is the accumulators' initial value
     if (DBG == 1 && p.stop_after == 1) { dump_x(row0); continue; }
     x2barrier();
+    ts(2);
     // ---------------- phase 2: q = LN2(h1) @ Wq^T -> X ----------------
     gemm5(smem + (4 * rg) * KS * 1024, X2_IC(KS));
+    ts(3);
     x2barrier();  // all waves are done reading X
     store_x(one4);
     if (DBG == 1 && p.stop_after == 2) { dump_x(row0); continue; }
     x2barrier();
+    ts(4);
     // ---------------- phase 3: text cross-attention, all heads, in place in X ----------------
     // unit = (16-row block, head): S^T = K q^T (6 key blocks x 2 d-steps), one-pass softmax over the lane's 24 keys and its 3
     // partner lanes, O^T = V^T P^T with P fed from the accumulator registers (the host arranges V^T's key order to match)
@@ -534,8 +549,10 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     acc_add_hres();
     if (DBG == 1 && p.stop_after == 3) { dump_x(row0); continue; }
     x2barrier();
+    ts(5);
     // ---------------- phase 4: h2 = a @ Wo2^T + b + h1;  X = LayerNorm3(h2) ----------------
     gemm5(smem + (4 * rg) * KS * 1024, X2_IC(KS));
+    ts(6);
     round_to_hres();
     if (DBG == 1 && p.stop_after == 14) { dump_hres(row0); continue; }
     layernorm_to_x();
@@ -543,6 +560,7 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     acc_add_hres();
     if (DBG == 1 && p.stop_after == 4) { dump_x(row0); continue; }
     x2barrier();
+    ts(7);
     // ---------------- phase 5: GEGLU feed-forward ----------------
     // every wave: [projection of chunk c | barrier | GELU of chunk c, output projection of chunk c - 1 | barrier] — group 1 one
     // barrier behind group 0, so that on every SIMD one wave multiplies a projection while its partner does GELU arithmetic
@@ -562,14 +580,22 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     f2(gb0 + ((NCH - 1) & 1) * G::GB_BYTES);
     x2barrier();
     if (!grp) x2barrier();
+    ts(8);
     // ---------------- phase 6: h3 -> X; acc = x + b_po; out = h3 @ Wpo^T + ... ----------------
     store_x(one4);  // (every wave's last read of X — the last projection — was at least one barrier ago)
     if (DBG == 1 && p.stop_after == 5) { dump_x(row0); continue; }
     acc_bias(4);
     acc_add_rows(x_srd, p.ldx, srow0);
     x2barrier();
+    ts(9);
     gemm5(smem + (4 * rg) * KS * 1024, X2_IC(KS));
+    ts(10);
     store_rows(row0);
+    ts(11);
+  }
+  if (DBG == 2 && (wave & 3) == 0 && lane == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<u16*>(p.h)) + ((long long)blockIdx.x * 2 + grp) * 16;
+    for (int i = 0; i < 12; ++i) dbg[i] = ta[i];
   }
 #endif
 }
@@ -822,7 +848,15 @@ int x2_launch_tail(int dtype, int stop_after, int grid, hipStream_t s, const Xf2
     }
     attr_set = true;
   }
-  if (stop_after) {  // debug instantiation (tests): intermediate dumps
+  if (stop_after == 99) {
+#ifdef DBIR_DIAG
+    if (x2_set_lds(&xf2_tail_kernel<F16, 2, CC>, LDS) != 0) return DBIR_ERR_LAUNCH;
+    hipLaunchKernelGGL((xf2_tail_kernel<F16, 2, CC>), dim3(grid), dim3(X2NT), LDS, s, p);
+#else
+    dbir_set_error("dbir_xf_tail: stop_after 99 (section timing) needs a DBIR_DIAG build");
+    return DBIR_ERR_ARG;
+#endif
+  } else if (stop_after) {  // debug instantiation (tests): intermediate dumps
     if (dtype == DBIR_F16) hipLaunchKernelGGL((xf2_tail_kernel<F16, 1, CC>), dim3(grid), dim3(X2NT), LDS, s, p);
     else hipLaunchKernelGGL((xf2_tail_kernel<BF16, 1, CC>), dim3(grid), dim3(X2NT), LDS, s, p);
   } else {
@@ -871,7 +905,7 @@ int dbir_xf2_tail_impl(int dtype, const void* attn_out, long long ldo, const voi
                        const void* kfrag, const void* vfrag, int Lk, float scale, int stop_after, void* stream) {
   const int BM = C == 320 ? X2Cfg<320>::BM : X2Cfg<640>::BM;
   DBIR_CHECK_ARG(M > 0 && L > 0 && L % BM == 0 && M % L == 0, "dbir_xf_tail: M %d must be whole samples of L %d rows, L %% %d == 0", M, L, BM);
-  DBIR_CHECK_ARG(stop_after == 0 || stop_after == 11 || stop_after == 14 || (stop_after >= 1 && stop_after <= 5),
+  DBIR_CHECK_ARG(stop_after == 0 || stop_after == 11 || stop_after == 14 || stop_after == 99 || (stop_after >= 1 && stop_after <= 5),
                  "dbir_xf_tail: stop_after %d is not a dump point of the second-generation kernel", stop_after);
   Xf2Params p;
   memset(&p, 0, sizeof(p));
