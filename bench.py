@@ -103,7 +103,7 @@ def parse(argv=None):
                          "1-GPU run of the default configuration (the driver's BENCH line), see --no-pmc")
     ap.add_argument("--no-pmc", action="store_true",
                     help="never run the PMC passes: roofline.traffic then comes from the committed pass of this batch "
-                         "(profiles/r5_pmc_traffic_b<batch>.json, else r4 / r3) and traffic_source says so")
+                         "(profiles/r6_pmc_traffic_b<batch>.json, else r5 / r4 / r3) and traffic_source says so")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the multi-GPU code path on however many ranks there are — with ONE rank: RCCL communicator "
                          "init, bucketed weight broadcast, one all-reduce per tiled evaluation, gather of the outputs on a "
@@ -228,7 +228,7 @@ def measure_roofline(cldm, device, batch, pmc=False):
         a[2] += 1
         a[3] += nbytes
     g = tot.get("gemm", [0.0, 1.0, 1, 0.0])
-    out = dict(bound="mfma", kernel="implicit-GEMM conv / linear family (gemm_halo / gemm_8p / gemm_glds / gemm_pers / gemm kernels, split-K reduce, fused transformer kernels xf_head / xf_tail)",
+    out = dict(bound="mfma", kernel="implicit-GEMM conv / linear family (gemm_halo / gemm_8p / gemm_glds / gemm_pers / gemm kernels, split-K reduce, fused transformer kernels xf2_head / xf2_tail)",
                achieved=g[0] / g[1] / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=g[0] / g[1] / MFMA_PEAK,
                traffic=None, launches=g[2], flops_per_eval=g[0], seconds_per_eval=g[1], eval_batch=2 * batch,
                avg_launch_us=g[1] / g[2] * 1e6, flops_per_launch=g[0] / g[2],
@@ -261,8 +261,8 @@ def measure_roofline(cldm, device, batch, pmc=False):
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
     if out["traffic"] is None:
-        pmc_file = os.path.join(ROOT, "profiles", f"r5_pmc_traffic_b{batch}.json")
-        for older in ("r4", "r3"):
+        pmc_file = os.path.join(ROOT, "profiles", f"r6_pmc_traffic_b{batch}.json")
+        for older in ("r5", "r4", "r3"):
             if not os.path.exists(pmc_file):
                 pmc_file = os.path.join(ROOT, "profiles", f"{older}_pmc_traffic_b{batch}.json")
         if os.path.exists(pmc_file):

@@ -28,8 +28,8 @@ from . import native, tuning
 
 ENABLED = os.environ.get("DBIR_AUTOTUNE", "1") != "0" and os.environ.get("DBIR_TUNING", "1") != "0"
 MIN_FLOPS = 0.5e9
-GENERIC = [5, 10, 14, 15, 25, 30, 34, 36, 37, 44, 45, 50, 52, 70, 71, 72, 73, 80, 280, 480]
-ALWAYS = [14, 15, 25, 36, 37, 50, 52, 70, 71, 72, 73, 80, 280, 480]
+GENERIC = [5, 10, 14, 15, 25, 30, 34, 36, 37, 44, 45, 50, 52, 70, 71, 72, 73, 80, 95, 280, 480]
+ALWAYS = [14, 15, 25, 36, 37, 50, 52, 70, 71, 72, 73, 80, 95, 280, 480]   # 95: register-streaming 64 x 80 (wins at M = 1024, K = 1280)
 # (the producer / consumer tiles 90 - 92 win 5 - 15 % on K >= 1280 linears timed alone and nothing / -2 % in the two-stream
 # evaluation, profiles/r3_pc_tiles_ab.txt: they are not offered to the timing-based choice)   # added behind a class's own winners (dbir_gemm refuses misfits)
 _cache: Optional[Dict[str, int]] = None

@@ -44,7 +44,7 @@ struct X2Cfg {
   static constexpr int X_BYTES = BM * CC * 2;         // 81920
   static constexpr int GB_BYTES = BM * CHH * 2;       // 16384
   static constexpr int B1_FLOATS = NCH * CG * 32;     // projection bias of every chunk: [chunk][column group][value | gate][16]
-  static constexpr int TAIL_LDS = X_BYTES + 2 * GB_BYTES + B1_FLOATS * 4;
+  static constexpr int TAIL_LDS = X_BYTES + 2 * GB_BYTES + (B1_FLOATS + 5 * CC) * 4;   // + the 5 bias rows
   static constexpr int HEAD_LDS = X_BYTES + 2 * CG * BM * 4;   // + LayerNorm exchange
   static_assert(GP % P == 0 && F1P % P == 0 && F2P % P == 0, "every sub-block must start at ring slot 0");
 };
@@ -164,9 +164,13 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
   prime();
   char* const gb0 = smem + G::X_BYTES;
   float* const b1l = reinterpret_cast<float*>(smem + G::X_BYTES + 2 * G::GB_BYTES);
-  // feed-forward projection bias -> LDS, once per workgroup
+  // feed-forward projection bias table and the 5 bias rows -> LDS, once per workgroup (global parameter loads in front of a GEMM
+  // were 1 - 2 us of exposed L2 latency each)
+  float* const brl = b1l + G::B1_FLOATS;
   for (int i = tid; i < G::B1_FLOATS / 4; i += X2NT)
     reinterpret_cast<f32x4*>(b1l)[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prm_srd, i * 16, 5 * C * 4, 0));
+  for (int i = tid; i < 5 * C / 4; i += X2NT)
+    reinterpret_cast<f32x4*>(brl)[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prm_srd, i * 16, 0, 0));
 
   // ---- acc[rb][j] += A[rows of this wave][k] W[columns of this wave][k] over KST k-steps of 32: A fragments from the operand
   //      image at `abase` (this wave's first row block), 5 weight pieces per k-step (ring period = 2 k-steps)
@@ -272,14 +276,16 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
   };
   // ---- accumulators := f32 parameter row `prow` (+ 16-bit residual rows from `srd`, row stride ld, first row r0)
   auto acc_bias = [&](int prow) __attribute__((always_inline)) {
+    const char* bp = reinterpret_cast<const char*>(brl) + (prow * C + 80 * cg) * 4 + x2opq(lg * 16);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prm_srd, x2opq(lg * 16) + 64 * j, (prow * C + 80 * cg) * 4, 0));
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 64 * j);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) acc[rb][j] = b;
     }
   };
-  auto acc_add_rows = [&](__amdgpu_buffer_rsrc_t srd, long long ld, long long r0) __attribute__((always_inline)) {
+  // 16-bit residual rows (row stride ld, first row r0) -> hres: issued in FRONT of a GEMM, added behind it (acc_add_hres)
+  auto load_rows_hres = [&](__amdgpu_buffer_rsrc_t srd, long long ld, long long r0) __attribute__((always_inline)) {
     const int vo = x2opq((int)((lr * ld + 4 * lg) * 2));
     const int so = (int)(((r0 + 64 * rg) * ld + 80 * cg) * 2);
 #pragma unroll
@@ -287,10 +293,8 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         const auto hv = __builtin_amdgcn_raw_buffer_load_b64(srd, vo + 32 * j, so + (int)(rb * 16 * ld * 2), 0);
-        acc[rb][j][0] += T::to_f32((u16)(hv[0] & 0xffff));
-        acc[rb][j][1] += T::to_f32((u16)(hv[0] >> 16));
-        acc[rb][j][2] += T::to_f32((u16)(hv[1] & 0xffff));
-        acc[rb][j][3] += T::to_f32((u16)(hv[1] >> 16));
+        hres[rb][j].x = hv[0];
+        hres[rb][j].y = hv[1];
       }
   };
   auto acc_add_hres = [&]() __attribute__((always_inline)) {
@@ -455,12 +459,13 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
         *reinterpret_cast<u32x4*>(smem + piece * 1024 + lane16) = v;
       }
     }
+    load_rows_hres(h_srd, p.ldh, srow0);  // (lands behind the GEMM)
     acc_bias(0);
-    acc_add_rows(h_srd, p.ldh, srow0);
     x2barrier();
     ts(0);
     // ---------------- phase 1: h1 = attn @ Wo1^T + b + h;  X = LayerNorm2(h1) ----------------
     gemm5(smem + (4 * rg) * KS * 1024, X2_IC(KS));
+    acc_add_hres();
     ts(1);
     round_to_hres();
     if (DBG == 1 && p.stop_after == 11) { dump_hres(row0); continue; }
@@ -480,68 +485,93 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     // ---------------- phase 3: text cross-attention, all heads, in place in X ----------------
     // unit = (16-row block, head): S^T = K q^T (6 key blocks x 2 d-steps), one-pass softmax over the lane's 24 keys and its 3
     // partner lanes, O^T = V^T P^T with P fed from the accumulator registers (the host arranges V^T's key order to match)
-    for (int u = wave; u < (BM / 16) * HEADS; u += 8) {
-      const int rbg = u / HEADS, hd = u - rbg * HEADS;
-      vec8 qf[2];
+    {
+      constexpr int NU = (BM / 16) * HEADS / 8;  // units per wave (5)
+      vec8 kfr[12], vfr[12];
+      auto unit = [&](int i, int& rbg, int& hd) __attribute__((always_inline)) {
+        const int u = wave + 8 * i;   // head-major: the waves work on (nearly) the same head at the same time
+        hd = u / (BM / 16);
+        rbg = u - hd * (BM / 16);
+      };
+      auto load_k = [&](int hd) __attribute__((always_inline)) {
+        const int so = (b * HEADS + hd) * 12 * 1024, vo = x2opq(lane16);
 #pragma unroll
-      for (int ds = 0; ds < 2; ++ds) qf[ds] = *reinterpret_cast<const vec8*>(smem + (rbg * KS + 2 * hd) * 1024 + x2opq(lane16) + ds * 1024);
-      const int kv_so = (b * HEADS + hd) * 12 * 1024;
-      const int kvo = x2opq(lane16);
-      f32x4 s[X2KB];
+        for (int i = 0; i < 12; ++i)
+          kfr[i] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(kf_srd, vo + (i & 3) * 1024, so + (i >> 2) * 4096, 0));
+      };
+      auto load_v = [&](int hd) __attribute__((always_inline)) {
+        const int so = (b * HEADS + hd) * 12 * 1024, vo = x2opq(lane16);
 #pragma unroll
-      for (int kb = 0; kb < X2KB; ++kb) {
-        const vec8 k0 = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(kf_srd, kvo + ((2 * kb) & 3) * 1024, kv_so + ((2 * kb) >> 2) * 4096, 0));
-        const vec8 k1 = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(kf_srd, kvo + ((2 * kb + 1) & 3) * 1024, kv_so + ((2 * kb + 1) >> 2) * 4096, 0));
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        s[kb] = T::mfma16(k0, qf[0], z);
-        s[kb] = T::mfma16(k1, qf[1], s[kb]);
-      }
-      vec8 vfr[12];
+        for (int i = 0; i < 12; ++i)
+          vfr[i] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(vf_srd, vo + (i & 3) * 1024, so + (i >> 2) * 4096, 0));
+      };
+      int rbg, hd;
+      unit(0, rbg, hd);
+      load_k(hd);
+      load_v(hd);
+      for (int ui = 0; ui < NU; ++ui) {
+        unit(ui, rbg, hd);
+        int rbn, hdn;
+        unit(ui + 1 < NU ? ui + 1 : ui, rbn, hdn);
+        vec8 qf[2];
 #pragma unroll
-      for (int i = 0; i < 12; ++i)
-        vfr[i] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(vf_srd, kvo + (i & 3) * 1024, kv_so + (i >> 2) * 4096, 0));
-      float mx = -1e30f;
+        for (int ds = 0; ds < 2; ++ds) qf[ds] = *reinterpret_cast<const vec8*>(smem + (rbg * KS + 2 * hd) * 1024 + x2opq(lane16) + ds * 1024);
+        f32x4 s[X2KB];
 #pragma unroll
-      for (int kb = 0; kb < X2KB; ++kb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int key = kb * 16 + 4 * lg + e;
-          const float sv = key < p.Lk ? s[kb][e] : -1e30f;
-          s[kb][e] = sv;
-          mx = fmaxf(mx, sv);
+        for (int kb = 0; kb < X2KB; ++kb) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          s[kb] = T::mfma16(kfr[2 * kb], qf[0], z);
+          s[kb] = T::mfma16(kfr[2 * kb + 1], qf[1], s[kb]);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float neg_m = -mx * p.c;
-      float psum = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        if (ui + 1 < NU) load_k(hdn);
+        __builtin_amdgcn_sched_barrier(0);
+        float mx = -1e30f;
 #pragma unroll
-      for (int kb = 0; kb < X2KB; ++kb)
+        for (int kb = 0; kb < X2KB; ++kb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][e], p.c, neg_m));
-          s[kb][e] = pv;
-          psum += pv;
+          for (int e = 0; e < 4; ++e) {
+            const int key = kb * 16 + 4 * lg + e;
+            const float sv = key < p.Lk ? s[kb][e] : -1e30f;
+            s[kb][e] = sv;
+            mx = fmaxf(mx, sv);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float neg_m = -mx * p.c;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < X2KB; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][e], p.c, neg_m));
+            s[kb][e] = pv;
+            psum += pv;
+          }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        f32x4 o[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ss = 0; ss < 3; ++ss) {
+          const uint4 pp = make_uint4(T::pack2(s[2 * ss][0], s[2 * ss][1]), T::pack2(s[2 * ss][2], s[2 * ss][3]),
+                                      T::pack2(s[2 * ss + 1][0], s[2 * ss + 1][1]), T::pack2(s[2 * ss + 1][2], s[2 * ss + 1][3]));
+          const vec8 pf = __builtin_bit_cast(vec8, pp);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) o[db] = T::mfma16(vfr[db * 3 + ss], pf, o[db]);
         }
-      psum += __shfl_xor(psum, 16, 64);
-      psum += __shfl_xor(psum, 32, 64);
-      f32x4 o[4];
+        __builtin_amdgcn_sched_barrier(0);
+        if (ui + 1 < NU) load_v(hdn);
+        __builtin_amdgcn_sched_barrier(0);
+        const float inv = 1.0f / psum;
 #pragma unroll
-      for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ss = 0; ss < 3; ++ss) {
-        const uint4 pp = make_uint4(T::pack2(s[2 * ss][0], s[2 * ss][1]), T::pack2(s[2 * ss][2], s[2 * ss][3]),
-                                    T::pack2(s[2 * ss + 1][0], s[2 * ss + 1][1]), T::pack2(s[2 * ss + 1][2], s[2 * ss + 1][3]));
-        const vec8 pf = __builtin_bit_cast(vec8, pp);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] = T::mfma16(vfr[db * 3 + ss], pf, o[db]);
-      }
-      const float inv = 1.0f / psum;
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        uint2 pk;
-        pk.x = T::pack2(o[db][0] * inv, o[db][1] * inv);
-        pk.y = T::pack2(o[db][2] * inv, o[db][3] * inv);
-        *reinterpret_cast<uint2*>(smem + rbg * KS * 1024 + (4 * hd) * 512 + x2opq(lanew) + db * 512) = pk;
+        for (int db = 0; db < 4; ++db) {
+          uint2 pk;
+          pk.x = T::pack2(o[db][0] * inv, o[db][1] * inv);
+          pk.y = T::pack2(o[db][2] * inv, o[db][3] * inv);
+          *reinterpret_cast<uint2*>(smem + rbg * KS * 1024 + (4 * hd) * 512 + x2opq(lanew) + db * 512) = pk;
+        }
       }
     }
     // acc = h1 + b_out2
@@ -558,6 +588,7 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     layernorm_to_x();
     acc_bias(3);  // acc = h2 + b_ff2
     acc_add_hres();
+    load_rows_hres(x_srd, p.ldx, srow0);  // the block input (residual of proj_out): lands somewhere behind the feed-forward
     if (DBG == 1 && p.stop_after == 4) { dump_x(row0); continue; }
     x2barrier();
     ts(7);
@@ -585,10 +616,10 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     store_x(one4);  // (every wave's last read of X — the last projection — was at least one barrier ago)
     if (DBG == 1 && p.stop_after == 5) { dump_x(row0); continue; }
     acc_bias(4);
-    acc_add_rows(x_srd, p.ldx, srow0);
     x2barrier();
     ts(9);
     gemm5(smem + (4 * rg) * KS * 1024, X2_IC(KS));
+    acc_add_hres();
     ts(10);
     store_rows(row0);
     ts(11);

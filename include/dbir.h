@@ -126,6 +126,13 @@ typedef struct dbir_gemm_desc {
                vmcnt; linear / 3x3 conv (stride 1 / 2, upsample) with K / Cin % 32 == 0, 16-bit row-major store, no
                GEGLU; split-K is reduced INSIDE the launch (write-through f32 slabs + arrival ticket, last arriver sums in
                slice order) and keeps the statistics stage; ws >= tiles * splitk * 327680 + tiles * 4 bytes.
+               93 - 97: register-streaming linear kernel (gemm_rs.hip, round 6): both operands straight into registers with
+               16-byte buffer loads (a lane reads 32 contiguous bytes of one row per k-step pair: whole 128-byte lines of the
+               row-major operands), 8 waves of 64 x 80 on 16x16x32 MFMAs tiling (RG x 64) x (CG x 80) x KSP k-slices summed
+               through LDS in slice order: 93 = 128x160 (2 slices), 94 = 64x160 (4), 95 = 64x80 (8), 96 = 128x320, 97 = 256x160;
+               dense linear, K % 64 == 0, M / N multiples of the tile, bias / residual epilogue only.  Measured (profiles/
+               r6_rs_ab.txt): 0.55 - 0.65x of the LDS kernels at M = 4096, 1.3x at M = 1024 x K = 1280 (tile 95) — offered to the
+               tuner for that class only.
                Ids 60 - 67 exist only in a DBIR_DIAG build (diagnostic ablations, meaningless outputs); 13, 74 - 79 and
                81 - 89 are invalid. */
   /* split-K (direct-to-LDS tiles >= 5 only; 0/1 = off): the K tiles are cut into `splitk` slices computed by different workgroups
@@ -243,7 +250,17 @@ int dbir_softmax_rows(int dtype, void* x, long long ld, long long rows, int L, v
  *   pair_bs > 0: attn / h / x hold only the DISTINCT samples [G * pair_bs] of a classifier-free-guidance batch whose
  *   halves were identical so far (Ms = M / 2); output sample b reads source sample (b / (2 pair_bs)) * pair_bs + b % pair_bs.
  *   stop_after (tests only, 0 in production): dump an intermediate into `out` instead — 11: h1, 1: normalised h1 (no
- *   affine), 2: q, 3: cross-attention output, 14: h2, 4: normalised h2, 5: h3; 99 / 103 - 105: timing instantiations. */
+ *   affine), 2: q, 3: cross-attention output, 14: h2, 4: normalised h2, 5: h3; 99 / 103 - 105: timing instantiations.
+ *
+ * Second generation (round 6, csrc/xformer2.hip): the same two entry points run kernels built around 8 waves x (64 rows x 80
+ * columns) on v_mfma_f32_16x16x32 with the weights streamed straight into registers when the weight stream passed has the
+ * second-generation length — dbir_xf2_geometry(C, &panel_rows, &head_bytes, &tail_bytes, &tail_prm_floats): per column group
+ * (80 output columns) one flat sequence of 1 KB pieces (16 columns x 32 k, lane 16 lg + lr = W[n0 + lr][32 ks + 8 lg .. + 8]) in
+ * consumption order + a copy of its first 10 pieces + 1 KB trailer (diffbir_amd/xformer.py: _pack_block_v2); tail prm = the 5
+ * bias rows followed by the feed-forward projection bias table [20 chunks][C / 80][value | gate][16]; kfrag / vfrag in the
+ * 16 x 16 fragment order (pack_context_frags, version 2).  Same arguments, same results (GELU by a sigmoid-form fit, max abs
+ * error 8.1e-5); stop_after 99 = section timing in a DBIR_DIAG build. */
+int dbir_xf2_geometry(int C, int* panel_rows, long long* head_bytes, long long* tail_bytes, int* tail_prm_floats);
 int dbir_xf_tile_bytes(void);
 int dbir_xf_head_tiles(void);
 int dbir_xf_tail_tiles(void);

@@ -60,6 +60,50 @@ LIN_CASES = [
 ]
 
 
+RS_CASES = [  # M, N, K, tile (register-streaming kernel, csrc/gemm_rs.hip: (RG x 64) x (CG x 80) tiles, K % 64 == 0)
+    (256, 320, 320, 93), (4096, 1280, 1280, 93), (128, 160, 64, 93), (1024, 1280, 1280, 94), (64, 160, 192, 94),
+    (1024, 1280, 1280, 95), (64, 80, 64, 95), (192, 240, 1280, 95), (512, 640, 640, 96), (128, 320, 5120, 96), (256, 160, 448, 97),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,tile", RS_CASES)
+@pytest.mark.parametrize("res", [False, True])
+def test_linear_register_streaming(M, N, K, tile, res, dtype):
+    """Tiles 93 - 97: both operands streamed straight into registers, k-slices summed through LDS in slice order; bias and
+    residual epilogue; strided input / output / residual views; bit-reproducible; misfit shapes are refused."""
+    w, b = torch.randn(N, K, generator=torch.Generator().manual_seed(K + N)) * K ** -0.5, torch.randn(N, generator=torch.Generator().manual_seed(N))
+    pw = ops.pack_linear(w, b, dtype, DEV)
+    xw = rnd(M, K + 16, dtype=dtype, seed=1)
+    x = xw[:, 8:8 + K]                                   # row stride K + 16, 16-byte aligned start
+    r = rnd(M, N + 8, dtype=dtype, seed=2)[:, :N] if res else None
+    outw = torch.zeros(M, N + 24, dtype=dtype, device=DEV)
+    out = outw[:, 16:16 + N]
+    ops.linear(x, pw, residual=r, out=out, tile=tile)
+    ref = x.float() @ w.to(DEV).to(dtype).float().t() + b.to(DEV)
+    if res:
+        ref = ref + r.float()
+    check(f"linear rs t{tile} M{M} N{N} K{K} res{int(res)}", out, ref.to(dtype), dtype, scale=2.0)
+    assert outw[:, :16].abs().max() == 0 and outw[:, 16 + N:].abs().max() == 0      # nothing outside the view touched
+    first = out.clone()
+    ops.linear(x, pw, residual=r, out=out, tile=tile)
+    assert torch.equal(out, first)
+
+
+def test_linear_register_streaming_rejects_misfits():
+    pw = ops.pack_linear(torch.randn(320, 96), torch.randn(320), torch.float16, DEV)
+    with pytest.raises(Exception):                                     # K % 64 != 0
+        ops.linear(rnd(128, 96), pw, tile=93)
+    pw = ops.pack_linear(torch.randn(200, 128), torch.randn(200), torch.float16, DEV)
+    with pytest.raises(Exception):                                     # N not a multiple of the tile width
+        ops.linear(rnd(128, 128), pw, tile=93)
+    pw = ops.pack_linear(torch.randn(160, 128), torch.randn(160), torch.float16, DEV)
+    with pytest.raises(Exception):                                     # M not a multiple of the tile height
+        ops.linear(rnd(100, 128), pw, tile=93)
+    with pytest.raises(Exception):                                     # activation epilogue
+        ops.linear(rnd(128, 128), pw, tile=93, act=ops.ACT_SILU)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,tile", LIN_CASES)
 def test_linear_plain(M, N, K, tile, dtype):

@@ -65,7 +65,7 @@ def _read_gemm(stream, t0, C):
 def test_weight_stream_is_what_the_kernel_reads(C):
     k = KCONST[C]
     w = _rand_block(C)
-    blk = xformer.pack_block(w, torch.float16, torch.device("cpu"))
+    blk = xformer.pack_block(w, torch.float16, torch.device("cpu"), version=1)
     assert tuple(blk.head_stream.shape) == (k["HEAD"], xformer.TILE_BYTES)
     assert tuple(blk.tail_stream.shape) == (k["TAIL"], xformer.TILE_BYTES)
     geo = xformer.geometry(C)
@@ -165,7 +165,7 @@ def test_context_fragments_are_what_the_kernel_reads(C):
     g = torch.Generator().manual_seed(3)
     k = torch.randn(B, Lk, C, generator=g).half()
     vt = torch.randn(B, C, 80, generator=g).half()
-    kf, vf = xformer.pack_context_frags(k, vt, Lk, heads)
+    kf, vf = xformer.pack_context_frags(k, vt, Lk, heads, version=1)
     assert tuple(kf.shape) == (B, heads, 3, 4, 64, 8) and tuple(vf.shape) == (B, heads, 2, 6, 64, 8)
     kn, vn, kfn, vfn = k.numpy(), vt.numpy(), kf.numpy(), vf.numpy()
     for b in range(B):
@@ -183,6 +183,140 @@ def test_context_fragments_are_what_the_kernel_reads(C):
                             key = 16 * s + 4 * hi + (p & 3) + 8 * (p >> 2)     # = where P sits in the S^T accumulators
                             exp = vn[b, 64 * h + 32 * t + lq, key] if key < Lk else np.float16(0)
                             assert vfn[b, h, t, s, lane, p] == exp
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# second-generation kernels (csrc/xformer2.hip), restated from the kernel source with its own constants:
+#   wave = (row group rg, column group cg): rows [64 rg, +64) x columns [80 cg, +80) as 4 x 5 blocks of 16 x 16; CG = C / 80
+#   a column group's stream = 1 KB pieces in consumption order; piece (16 columns n0.., k-step ks of 32): lane 16 lg + lr holds
+#   W[n0 + lr][32 ks + 8 lg .. + 8]
+#   gemm5: for ks: pieces j = 0..4 = columns 80 cg + 16 j
+#   feed-forward order: F1(0), [F1(c), F2(c - 1)] c = 1 .. 19, F2(19); F1(c): for ks: (value, gate) of hidden units
+#   16 CG c + 16 cg ..+16; F2(c): for k in range(GK = CG / 2): pieces j = 0..4, k-step (16 CG c) / 32 + k of ff.net.2
+#   stream = out1, q2, out2, feed-forward, proj_out (tail) / proj_in, q, k, v (head), + a copy of the first 10 pieces, + 1 KB trailer
+def _v2_streams(raw, CG, pieces):
+    body = raw.numpy()[:-1024].view(np.float16).reshape(CG, pieces + xformer.V2_RING, 64, 8)
+    for cg in range(CG):
+        assert np.array_equal(body[cg, pieces:], body[cg, :xformer.V2_RING])   # ring wrap copy
+    return body
+
+
+def _v2_read_gemm(st, p0, C):
+    """W[n][k] as gemm5 multiplies it, from pieces p0 .. of every column group."""
+    CG, KS = C // 80, C // 32
+    W = np.zeros((C, C), np.float16)
+    for cg in range(CG):
+        for ks in range(KS):
+            for j in range(5):
+                frag = st[cg, p0 + 5 * ks + j]
+                for lane in range(64):
+                    lr, lg = lane & 15, lane >> 4
+                    W[80 * cg + 16 * j + lr, 32 * ks + 8 * lg:][:8] = frag[lane]
+    return W
+
+
+@pytest.mark.parametrize("C", [320, 640])
+def test_weight_stream_v2_is_what_the_kernel_reads(C):
+    CG, KS = C // 80, C // 32
+    NCH, GK, GP = 20, CG // 2, 5 * (C // 32)
+    w = _rand_block(C, seed=2)
+    blk = xformer.pack_block(w, torch.float16, torch.device("cpu"), version=2)
+    assert blk.version == 2
+    head_pieces, tail_pieces = 4 * GP, 4 * GP + NCH * (2 * KS + 5 * GK)
+    assert blk.head_stream.numel() == CG * (head_pieces + 10) * 1024 + 1024
+    assert blk.tail_stream.numel() == CG * (tail_pieces + 10) * 1024 + 1024
+    # the two generations are told apart by their stream lengths (csrc/xformer.hip dispatch): never equal
+    v1 = xformer.pack_block(w, torch.float16, torch.device("cpu"), version=1)
+    assert v1.head_stream.numel() != blk.head_stream.numel() and v1.tail_stream.numel() != blk.tail_stream.numel()
+    hs, ts = _v2_streams(blk.head_stream, CG, head_pieces), _v2_streams(blk.tail_stream, CG, tail_pieces)
+    h16 = lambda n: w[n].half().numpy()  # noqa: E731
+    fw = lambda n, ln: (w[n] * w[ln + ".w"][None, :]).half().numpy()  # noqa: E731
+    fb = lambda n, ln: (w[n] @ w[ln + ".b"]).numpy()                   # noqa: E731
+    for i, exp in enumerate((h16("proj_in.w"), fw("q1.w", "norm1"), fw("k1.w", "norm1"), fw("v1.w", "norm1"))):
+        assert np.array_equal(_v2_read_gemm(hs, GP * i, C), exp), i
+    ff0 = 3 * GP
+    for p0, exp in ((0, h16("out1.w")), (GP, fw("q2.w", "norm2")), (2 * GP, h16("out2.w")),
+                    (ff0 + NCH * (2 * KS + 5 * GK), h16("proj_out.w"))):
+        assert np.array_equal(_v2_read_gemm(ts, p0, C), exp), p0
+    w1, b1, w2 = fw("ff1.w", "norm3"), (w["ff1.b"] + w["ff1.w"] @ w["norm3.b"]).numpy(), h16("ff2.w")
+    F1P, F2P = 2 * KS, 5 * GK
+
+    def f1_pos(c):   # F1(0) F1(1) F2(0) F1(2) F2(1) ...
+        return ff0 + (0 if c == 0 else F1P + (c - 1) * (F1P + F2P))
+
+    def f2_pos(c):
+        return ff0 + (NCH * F1P + (NCH - 1) * F2P if c == NCH - 1 else 2 * F1P + c * (F1P + F2P))
+
+    prm = blk.tail_prm.numpy()
+    b1t = prm[5 * C:].reshape(NCH, CG, 2, 16)
+    for c in (0, 1, 7, 19):
+        for cg in range(CG):
+            h0 = 16 * CG * c + 16 * cg
+            val, gate = np.zeros((16, C), np.float16), np.zeros((16, C), np.float16)
+            for ks in range(KS):
+                for nb, dst in ((0, val), (1, gate)):
+                    frag = ts[cg, f1_pos(c) + 2 * ks + nb]
+                    for lane in range(64):
+                        lr, lg = lane & 15, lane >> 4
+                        dst[lr, 32 * ks + 8 * lg:][:8] = frag[lane]
+            assert np.array_equal(val, w1[h0:h0 + 16]) and np.array_equal(gate, w1[4 * C + h0:4 * C + h0 + 16])
+            assert np.array_equal(b1t[c, cg, 0], b1[h0:h0 + 16]) and np.array_equal(b1t[c, cg, 1], b1[4 * C + h0:4 * C + h0 + 16])
+            got = np.zeros((80, 16 * CG), np.float16)
+            for k in range(GK):
+                for j in range(5):
+                    frag = ts[cg, f2_pos(c) + 5 * k + j]
+                    for lane in range(64):
+                        lr, lg = lane & 15, lane >> 4
+                        got[16 * j + lr, 32 * k + 8 * lg:][:8] = frag[lane]
+            assert np.array_equal(got, w2[80 * cg:80 * cg + 80, 16 * CG * c:16 * CG * (c + 1)])
+    for row, exp in enumerate((w["out1.b"].numpy(), fb("q2.w", "norm2"), w["out2.b"].numpy(), w["ff2.b"].numpy(),
+                               w["proj_out.b"].numpy())):
+        assert np.array_equal(prm[row * C:(row + 1) * C], exp), row
+
+
+def test_operand_image_offsets_v2_are_consistent():
+    """xformer2.hip: the 4 consecutive columns a lane holds of 16-column block t of row block rbg are written at
+    rbg * KST * 1024 + t * 512 + lanew and read back by the fragment read (rbg * KST + ks) * 1024 + lane * 16 as columns
+    32 ks + 8 lg + e of row lr."""
+    for kst, nrb in ((10, 8), (2, 8), (20, 4), (4, 4)):   # X / chunk image at C = 320, at C = 640
+        seen = set()
+        for rbg in range(nrb):
+            for t in range(2 * kst):
+                for lane in range(64):
+                    lr, lg = lane & 15, lane >> 4
+                    off = rbg * kst * 1024 + t * 512 + (lg >> 1) * 256 + lr * 16 + (lg & 1) * 8
+                    col = 16 * t + 4 * lg                  # first of the lane's 4 columns
+                    ks, lgr, e0 = col // 32, (col % 32) // 8, col % 8
+                    assert off == (rbg * kst + ks) * 1024 + (lgr * 16 + lr) * 16 + e0 * 2
+                    assert off not in seen
+                    seen.add(off)
+        assert len(seen) * 8 == nrb * 16 * 32 * kst * 2
+
+
+@pytest.mark.parametrize("C", [320, 640])
+def test_context_fragments_v2_are_what_the_kernel_reads(C):
+    B, heads, Lk = 2, C // 64, 77
+    g = torch.Generator().manual_seed(3)
+    k = torch.randn(B, Lk, C, generator=g).half()
+    vt = torch.randn(B, C, 80, generator=g).half()
+    kf, vf = xformer.pack_context_frags(k, vt, Lk, heads, version=2)
+    assert tuple(kf.shape) == (B, heads, 6, 2, 64, 8) and tuple(vf.shape) == (B, heads, 4, 3, 64, 8)
+    kn, vn, kfn, vfn = k.numpy(), vt.numpy(), kf.numpy(), vf.numpy()
+    for b in range(B):
+        for h in range(heads):
+            for lane in range(64):
+                lr, lg = lane & 15, lane >> 4
+                for kb in range(6):       # S^T block kb: A operand row = key 16 kb + lr, k = d 32 ds + 8 lg + e
+                    for ds in range(2):
+                        key = 16 * kb + lr
+                        exp = kn[b, key, 64 * h + 32 * ds + 8 * lg:][:8] if key < Lk else np.zeros(8, np.float16)
+                        assert np.array_equal(kfn[b, h, kb, ds, lane], exp)
+                for db in range(4):       # O^T block db: A operand row = d 16 db + lr; element i of key-step ss = the key whose
+                    for ss in range(3):   # probability sits in element i of the lane's P fragment: blocks 2 ss, 2 ss + 1, keys 4 lg + e
+                        for i in range(8):
+                            key = 32 * ss + 16 * (i >> 2) + 4 * lg + (i & 3)
+                            exp = vn[b, 64 * h + 16 * db + lr, key] if key < Lk else np.float16(0)
+                            assert vfn[b, h, db, ss, lane, i] == exp
 
 
 def _small_unet(ch=320):

@@ -26,7 +26,7 @@ def read(outdir, counter):
 
 
 def family(name):
-    if "gemm_" in name or "gemm8p_" in name or "splitk_reduce" in name or "xf_head_kernel" in name or "xf_tail_kernel" in name:
+    if "gemm_" in name or "gemm8p_" in name or "splitk_reduce" in name or "xf_head_kernel" in name or "xf_tail_kernel" in name or "xf2_head_kernel" in name or "xf2_tail_kernel" in name:
         return "gemm"   # the implicit-GEMM family incl. the fused transformer kernels (bench.py counts them in it)
     if "attn" in name:
         return "attention"

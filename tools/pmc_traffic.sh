@@ -14,7 +14,7 @@ OUT=$(cd "$OUT" && pwd)
 cd /tmp
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "gemm|attn|gn_|ln_kernel|ln2_kernel|splitk|xf_" --output-format csv -d "$OUT/$C" -o pmc -- \
+  rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "gemm|attn|gn_|ln_kernel|ln2_kernel|splitk|xf_|xf2_" --output-format csv -d "$OUT/$C" -o pmc -- \
     python "$REPO/tools/profile_eval.py" --pmc-mode --pair --batch $BATCH > "$OUT/$C.log" 2>&1 || { tail -5 "$OUT/$C.log"; exit 1; }
 done
 cd "$REPO"
