@@ -71,9 +71,9 @@ PARITY = {
           "(full_c3_dpm20_b4.npz; that oracle reproduces the reference's C2 / C4 goldens to 86 / 84 dB, max 1 LSB)",
     "c4": "fp16, bar 45 dB: 57.2 dB on 2048x2048, 49 tiles x 50 steps against the fp32 oracle on the GPU "
           "(full_c4_tiled2048_spaced50.npz); 56.4 dB on the 10-step golden of the unmodified reference",
-    "c5": "bf16, bar max(34 dB, the reference's OWN bf16-vs-fp32 PSNR - 1.5 dB = 38.9 dB) (north_star states 45 dB for fp16 only): "
-          "45.5 dB on one 4096x4096 image, 225 tiles x 50 steps, against the fp32 oracle on the GPU "
-          "(full_c5_tiled4096_spaced50.npz)",
+    "c5": "bf16: 45.5 dB on one 4096x4096 image, 225 tiles x 50 steps, against the fp32 oracle on the GPU "
+          "(full_c5_tiled4096_spaced50.npz) — also above north_star's fp16 bar of 45 dB; the test's own bf16 bar is "
+          "max(34 dB, the reference's OWN bf16-vs-fp32 PSNR - 1.5 dB = 38.9 dB, a yardstick recorded on a 768x768 / 3-step case)",
 }
 
 

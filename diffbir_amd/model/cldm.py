@@ -76,6 +76,7 @@ class ControlLDM:
         self._graphs: "OrderedDict[tuple, _EvalGraph]" = OrderedDict()
         self._graph_pool = None
         self.max_graphs = 6
+        self.max_graph_rows = 2 * self.graph_auto_rows
 
     # ---- weights ------------------------------------------------------------------------------
     @torch.no_grad()
@@ -162,7 +163,9 @@ class ControlLDM:
         key = (tuple(x_noisy.shape), str(x_noisy.device), cond.get("cfg_pair"), id(kvu), id(kvc), tuple(c_txt.shape),
                tuple(float(s) for s in self.control_scales), str(self.unet._dtype), bool(self.overlap_streams),
                self.unet._gen, self.controlnet._gen)
-        key = key + (bool(self.use_plan),)
+        # (split-K workspaces are keyed by the stream current at call time and a recorded plan embeds their raw
+        #  pointers — a replay under ANOTHER current stream must not share a replay recorded under this one)
+        key = key + (bool(self.use_plan), torch.cuda.current_stream(x_noisy.device).cuda_stream if x_noisy.is_cuda else 0)
         g = self._graphs.get(key)
         if g is None:
             try:
@@ -171,9 +174,15 @@ class ControlLDM:
                 warnings.warn(f"diffbir_amd: HIP graph capture of the network evaluation failed ({e!r}); "
                               "continuing with eager launches")
                 self.use_graph = False
+                self.reset_graphs()   #  release the pools the kept replays pin: the eager fallback needs the memory
                 return self._forward_eager(x_noisy, t, cond)
+            g.rows = int(x_noisy.shape[0] * x_noisy.shape[-2] * x_noisy.shape[-1])
             self._graphs[key] = g
-            while len(self._graphs) > self.max_graphs:
+            # bounded by count AND by size (every _EvalPlan pins the activations of one evaluation in its own pool, and
+            # `graph_auto_rows` admits evaluations of up to 64 samples): the newest replay always stays, older ones go while the
+            # kept latent pixels exceed two of the largest admissible evaluations
+            while len(self._graphs) > self.max_graphs or \
+                    (len(self._graphs) > 1 and sum(getattr(v, "rows", 0) for v in self._graphs.values()) > self.max_graph_rows):
                 self._graphs.popitem(last=False)
         else:
             self._graphs.move_to_end(key)

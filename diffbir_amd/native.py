@@ -54,6 +54,7 @@ SIGNATURES = {
     "dbir_groupnorm_affine": [_I, _P, _LL, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "dbir_layernorm": [_I, _P, _LL, _P, _LL, _P, _P, _I, _I, _I, _F, _P],
     "dbir_xf_tile_bytes": [], "dbir_xf_head_tiles": [], "dbir_xf_tail_tiles": [], "dbir_xf_geometry": [_I, _P, _P, _P],
+    "dbir_xf2_geometry": [_I, _P, _P, _P, _P],
     "dbir_xf_head": [_I, _P, _LL, _P, _P, _LL, _P, _LL, _P, _LL, _LL, _I, _I, _I, _P, _LL, _P, _P],
     "dbir_xf_tail": [_I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _P, _LL, _P, _P, _P, _I, _F, _I, _P],
     "dbir_softmax_rows": [_I, _P, _LL, _LL, _I, _P],

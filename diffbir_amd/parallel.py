@@ -75,7 +75,15 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
             device = torch.device("cpu")
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        if "MASTER_PORT" not in os.environ:
+            #  a default port only for the forced ONE-rank group, and a free one (two such jobs on a host must not
+            # collide); a multi-rank launch that forgot MASTER_PORT fails loudly instead of meeting strangers on a shared default
+            if world > 1:
+                raise RuntimeError("init_distributed: WORLD_SIZE > 1 needs MASTER_PORT (launch through torch.distributed.run)")
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         be = backend or ("nccl" if device.type == "cuda" else "gloo")
         kw = dict(device_id=device) if be == "nccl" else {}
         dist.init_process_group(be, rank=rank, world_size=world, **kw)

@@ -90,7 +90,10 @@ def test_gpu_count_parity_strict_without_tuned_tiles(tmp_path, monkeypatch):
     """the 50 dB bar above tolerates what tuned per-batch tiles do; a real sharding bug (wrong noise rows)
     could hide under it.  With the tile table and the first-use autotune OFF the C heuristic picks tiles from the problem
     class only where M-independent, and with the epilogue statistics off every GroupNorm reads the stored tensor: the per
-    sample arithmetic is then the same for a rank's batch of 2 and the full batch of 4 -> bit-identical outputs."""
+    sample arithmetic is then the same for a rank's batch of 2 and the full batch of 4.  EXPECTED: bit-identical outputs.
+    ASSERTED: >= 60 dB with the per-image identity list in the message — this test has never run (no 2-GPU box was
+    available to any round), so the bar stays at what a correct sharding cannot miss; tighten it to `all(same)` once a
+    run has shown the expectation to hold."""
     import numpy as np
     monkeypatch.setenv("DBIR_AUTOTUNE", "0")
     monkeypatch.setenv("DBIR_TUNING", "0")
