@@ -42,7 +42,7 @@ TILE_W, TILE_AUX = 20480, 512
 TILE_BYTES = TILE_W + TILE_AUX
 HEAD_TILES, TAIL_TILES = 40, 160            # C = 320
 LK_PAD = 96
-MIN_PANELS_640 = 160   # C = 640: 64-row panels, one per CU — below ~160 panels the per-launch kernels win (idle CUs)
+MIN_PANELS_640 = int(os.environ.get("DBIR_XF_MIN_PANELS_640", "128"))   # C = 640: 64-row panels, one per CU — below ~128 panels (half the CUs idle) the per-launch kernels win; 160 until round 6 (second-generation tail: 187 us fused against 240 per launch at 128 panels)
 # Kernel generation the weights are packed for (the C side picks its kernels by the stream length):
 #   2 (default, round 6) = csrc/xformer2.hip — 8 waves x (64 rows x 80 columns) on v_mfma_f32_16x16x32, weights streamed
 #       straight into registers: per column group one flat sequence of 1 KB pieces (16 output columns x 32 k, lane
