@@ -1009,6 +1009,47 @@ def test_xf_tail(C, B, L, dtype):
         assert torch.equal(ops.xf_tail(attn, h, x, blk, kf, vf, Lk, scale, L), full), f"not reproducible ({it})"
 
 
+@pytest.mark.parametrize("C,B,L", [(320, 16, 4096), (640, 16, 1024)])
+def test_xf_race_screen_full_chip(C, B, L):
+    """VERDICT r5 #1 'race screen at full-chip size x 100': the second-generation tail / head at the benchmark's shape (every CU
+    busy, two panels per workgroup at C = 320), 100 launches each, every result bit-identical to the first — the two wave groups
+    run one barrier apart and exchange the GEGLU chunks / LayerNorm partials through LDS, the weight ring wraps between panels."""
+    dtype, heads, Lk = torch.float16, C // 64, 77
+    blk = ops.pack_xf_block(_xf_weights(seed=5, C=C), dtype, DEV)
+    attn, h = rnd(B * L, C, dtype=dtype, seed=1), rnd(B * L, C, dtype=dtype, seed=2)
+    side = 64 if C == 320 else 32
+    x = rnd(B, side, side, C, dtype=dtype, seed=3)
+    k, vt = rnd(B, Lk, C, dtype=dtype, seed=4), rnd(B, C, 80, dtype=dtype, seed=5)
+    kf, vf = ops.pack_context_frags(k, vt, Lk, heads)
+    first = ops.xf_tail(attn, h, x, blk, kf, vf, Lk, 0.125, L).clone()
+    assert torch.isfinite(first.float()).all()
+    ab = ops.groupnorm_affine(x, torch.ones(C, device=DEV), torch.zeros(C, device=DEV), 1e-6)
+    h0, qk0, vt0 = (t.clone() for t in ops.xf_head(x, ab, blk, L))
+    out = torch.empty_like(first)
+    for it in range(100):
+        ops.xf_tail(attn, h, x, blk, kf, vf, Lk, 0.125, L, out=out)
+        assert torch.equal(out, first), f"xf_tail differs at launch {it}"
+        hh, qk, vv = ops.xf_head(x, ab, blk, L)
+        assert torch.equal(hh, h0) and torch.equal(qk, qk0) and torch.equal(vv, vt0), f"xf_head differs at launch {it}"
+
+
+@pytest.mark.parametrize("Lk", [1, 16, 40, 96])
+@pytest.mark.parametrize("C", [320, 640])
+def test_xf_tail_context_lengths(C, Lk):
+    """Text contexts other than 77 tokens: the key mask of the fused cross-attention (keys >= Lk) at the edges of its 16-key blocks."""
+    dtype, heads, B, L = torch.float16, C // 64, 2, 256 if C == 320 else 192
+    blk = ops.pack_xf_block(_xf_weights(seed=2, C=C), dtype, DEV)
+    attn, h = rnd(B * L, C, dtype=dtype, seed=1), rnd(B * L, C, dtype=dtype, seed=2)
+    x = rnd(B, L // 64, 64, C, dtype=dtype, seed=3)
+    k, vt = rnd(B, Lk, C, dtype=dtype, seed=4), rnd(B, C, 96, dtype=dtype, seed=5)
+    kf, vf = ops.pack_context_frags(k, vt, Lk, heads)
+    ek, ev = emu.pack_context_frags(k, vt, Lk, heads)
+    for code, name in ((3, "cross-attn"), (0, "out")):
+        got = ops.xf_tail(attn, h, x, blk, kf, vf, Lk, 0.125, L, stop_after=code)
+        ref = emu.xf_tail(attn, h, x, blk, ek, ev, Lk, 0.125, L, stop_after=code)
+        check(f"xf_tail Lk {Lk} {name}", got, ref, dtype, scale=2.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_xf_tail_pairs_and_strided_output(dtype):
     """Shared CFG prefix: inputs hold the distinct samples, the output the full batch with per-half text context; output

@@ -19,7 +19,7 @@ import bench  # noqa: E402
 from diffbir_amd import native, ops, tuning  # noqa: E402
 
 CANDIDATES = [5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 25, 26, 30, 32, 34, 35, 36, 37, 38, 40, 41, 44, 45, 50, 51, 52, 53, 70, 71, 72, 73,
-              80, 90, 91, 92]   # tile ids (include/dbir.h)
+              80, 90, 91, 92, 95]   # tile ids (include/dbir.h); 95 = register-streaming 64 x 80 (gemm_rs.hip)
 SPLITK = [(10, 2), (10, 3), (10, 4), (10, 6), (10, 9), (12, 2), (12, 3), (12, 4), (5, 2), (5, 3), (14, 2), (14, 3), (14, 4),
           (15, 2), (15, 3), (30, 2), (30, 3), (30, 4), (30, 6), (30, 9), (32, 2), (32, 3), (25, 2), (25, 3), (34, 2), (34, 3),
           (34, 4), (35, 2), (35, 3), (36, 2), (36, 3), (37, 2), (37, 3), (37, 4), (40, 2), (40, 3), (40, 4), (40, 6),
