@@ -21,7 +21,10 @@ void dbir_xf_set_variant(int v);         // xformer.hip
 extern "C" int dbir_set_option(int key, int value) {
   switch (key) {
     case DBIR_OPT_ATTN_VARIANT:
-      DBIR_CHECK_ARG(value >= 2 && value <= 6, "dbir_set_option: attention variant must be 2 (default), 3 (generic kernel only), 4 / 5 / 6 (generic kernel with the pre-round-4 softmax at 4 / 3 / default waves per SIMD)");
+      DBIR_CHECK_ARG((value >= 2 && value <= 8) || (value >= 1000 && value <= 1000 + (1 << 20)),
+                     "dbir_set_option: attention variant must be 2 (default), 3 (no LDS-resident cross kernel), 4 / 5 / 6 (4-wave kernel with the "
+                     "pre-round-4 softmax at 4 / 3 / default waves per SIMD), 8 (the 8-wave attn3 experiment for long self-attentions), or 1000 + n "
+                     "(query-row threshold of attn3)");
       dbir_attention_set_variant(value);
       return DBIR_OK;
     case DBIR_OPT_XF_VARIANT:

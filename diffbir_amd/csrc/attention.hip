@@ -316,6 +316,214 @@ __global__ __launch_bounds__(256, OCC) void attn2_kernel(const u16* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// attn3_kernel (round 6): the same arithmetic as attn2_kernel<T, *, FOLD = true> with EIGHT waves per workgroup (256 query
+// rows) whose two wave groups (waves 0-3 / 4-7 = one wave of each on every SIMD) run ONE BARRIER APART.
+// Why: per 64-key tile a wave issues 16 MFMAs (512 matrix cycles) and ~740 cycles of softmax VALU work, and on this chip
+// the VALU and MFMA work of ONE wave do not overlap (profiles/r3_mfma_valu_overlap.txt, r6_ff64_gateA_v1.txt: a wave's own
+// MFMAs hide none of its VALU instructions) while two waves of a SIMD overlap fully IF one is in its matrix phase while the
+// other is in its VALU phase.  Independent workgroups (attn2: 2 - 3 resident per CU) drift in and out of that alignment:
+// 1400 SIMD cycles per tile measured = the serial sum.  Here the alignment is constructed: every wave alternates
+//   matrix part : O^T += V^T P^T of tile t - 1, S^T = K Q^T of tile t, write its share of tile t + 1 into LDS, fetch t + 2
+//   barrier
+//   VALU part   : softmax of tile t (running maximum, exponentials, packing, row sum)
+//   barrier
+// and group 1 executes one barrier more in front of the loop (group 0 one behind it): in every barrier interval one wave
+// of each SIMD multiplies while its partner exponentiates.  K / V^T tiles live in a 3-deep LDS ring (a tile is read by the
+// two groups in consecutive intervals; its slot is rewritten two tiles later).
+template <typename T>
+__global__ __launch_bounds__(512) void attn3_kernel(const u16* __restrict__ Q, long long q_bs, long long ldq,
+                                                    const u16* __restrict__ K, long long k_bs, long long ldk,
+                                                    const u16* __restrict__ Vt, long long vt_bs, long long ldvt,
+                                                    u16* __restrict__ O, long long o_bs, long long ldo, int H, int Lq,
+                                                    int Lk, float c /* scale * log2(e) */) {
+  constexpr int KS_HALFS = KT * K_LD, VS_HALFS = 64 * V_LD, NB = 3;
+  __shared__ __attribute__((aligned(16))) u16 lds[NB * (KS_HALFS + VS_HALFS)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int nqb = (Lq + 255) / 256;
+  int bh, qb;
+  {
+    const int w = blockIdx.x, BH = gridDim.x / nqb;
+    if ((BH & 7) == 0) {  // all query blocks of one (batch, head) on one XCD: its K / V^T are fetched from HBM once
+      const int xcd = w & 7, idx = w >> 3;
+      bh = xcd + 8 * (idx / nqb);
+      qb = idx % nqb;
+    } else {
+      bh = w / nqb;
+      qb = w % nqb;
+    }
+  }
+  const int b = bh / H, h = bh % H;
+  const int q_row = qb * 256 + wave * 32 + lq;
+  const bool q_ok = q_row < Lq;
+
+  typename T::vec8 qf[4];
+  {
+    const u16* qp = Q + (long long)b * q_bs + (long long)(q_ok ? q_row : 0) * ldq + h * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 v = q_ok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0);
+      float f[8];
+      unpack8<T>(v, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= c;
+      qf[ks] = __builtin_bit_cast(typename T::vec8, pack8<T>(f));
+    }
+  }
+  f32x16 negm;  // -m_run in every element = the C operand of the first MFMA of each score block
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  f32x16 o_acc[2], s_acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[t][r] = 0.f;
+  float m_run = 0.f, l_run = 0.f;
+  uint4 pp[4];  // the tile's probabilities, packed: B operands of the four key-steps of O^T += V^T P^T
+
+  const u16* Kg = K + (long long)b * k_bs + h * 64;
+  const u16* Vg = Vt + (long long)b * vt_bs + (long long)(h * 64) * ldvt;
+  const int kc = tid & 7, row = tid >> 3;  // one 16-byte chunk of the K tile and one of the V^T tile per thread
+  const int ntiles = (Lk + KT - 1) / KT;
+  uint4 kreg, vreg;
+  auto fetch = [&](int kt) {
+    const int key0 = kt * KT;
+    kreg = make_uint4(0, 0, 0, 0);
+    if (key0 + row < Lk) kreg = *reinterpret_cast<const uint4*>(Kg + (long long)(key0 + row) * ldk + kc * 8);
+    vreg = make_uint4(0, 0, 0, 0);
+    if (key0 + kc * 8 < Lk) vreg = *reinterpret_cast<const uint4*>(Vg + (long long)row * ldvt + key0 + kc * 8);
+  };
+  auto commit = [&](int kt) {
+    u16* Ks = lds + (kt % NB) * (KS_HALFS + VS_HALFS);
+    u16* Vs = Ks + KS_HALFS;
+    const int kcol = kt * KT + kc * 8;
+    if (kt * KT + KT > Lk) {  // ragged last tile: pad columns of V^T may hold anything -> zero keys >= Lk
+      u16* hv = reinterpret_cast<u16*>(&vreg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (kcol + e >= Lk) hv[e] = 0;
+    }
+    *reinterpret_cast<uint4*>(&Ks[row * K_LD + kc * 8]) = kreg;
+    uint2* dst = reinterpret_cast<uint2*>(&Vs[row * V_LD + kc * 8]);
+    dst[0] = make_uint2(vreg.x, vreg.y);
+    dst[1] = make_uint2(vreg.z, vreg.w);
+  };
+  auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto pv = [&](int kt) {  // O^T += V^T P^T of tile kt
+    const u16* Vs = lds + (kt % NB) * (KS_HALFS + VS_HALFS) + KS_HALFS;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 p4 = pp[s];
+      const typename T::vec8 pfrag = __builtin_bit_cast(typename T::vec8, p4);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u16* vrow = &Vs[(t * 32 + lq) * V_LD + 16 * s + 4 * hi];
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+        const uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        o_acc[t] = T::mfma32(__builtin_bit_cast(typename T::vec8, vv), pfrag, o_acc[t]);
+      }
+    }
+  };
+
+  fetch(0);
+  commit(0);
+  if (ntiles > 1) fetch(1);
+  bar();
+  if (grp) bar();  // group 1 runs one barrier behind group 0
+  for (int kt = 0; kt < ntiles; ++kt) {
+    // ---------------- matrix part ----------------
+    if (kt > 0) pv(kt - 1);
+    {
+      const u16* Ks = lds + (kt % NB) * (KS_HALFS + VS_HALFS);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          typename T::vec8 kf = *reinterpret_cast<const typename T::vec8*>(&Ks[(kb * 32 + lq) * K_LD + ks * 16 + hi * 8]);
+          if (ks == 0) s_acc[kb] = T::mfma32(kf, qf[0], negm);
+          else s_acc[kb] = T::mfma32(kf, qf[ks], s_acc[kb]);
+        }
+    }
+    if (kt + 1 < ntiles) {
+      commit(kt + 1);
+      if (kt + 2 < ntiles) fetch(kt + 2);
+    }
+    bar();
+    // ---------------- VALU part ----------------
+    const int key0 = kt * KT;
+    if (key0 + KT > Lk) {  // ragged last tile: mask keys >= Lk (wave-uniform branch)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= Lk) s_acc[kb][r] = -1e30f;
+        }
+    }
+    float mx = s_acc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // the accumulators hold s*c - m_run.  First tile: m_run := the row maximum; later: rescale only when some row's maximum
+    // grew by more than 2^8 (attn2_kernel's rule)
+    if (kt == 0 || !__all(mx <= 8.0f)) {
+      const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+      m_run += delta;
+      if (kt != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        l_run *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o_acc[t][r] *= alpha;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[kb][r] -= delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float pf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = __builtin_amdgcn_exp2f(s_acc[s >> 1][8 * (s & 1) + j]);
+      pp[s] = pack8<T>(pf);
+      psum = dot2_ones<T>(pp[s].w, dot2_ones<T>(pp[s].z, dot2_ones<T>(pp[s].y, dot2_ones<T>(pp[s].x, psum))));
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run += psum;
+    bar();
+  }
+  pv(ntiles - 1);
+  if (!grp) bar();
+
+  if (q_ok) {
+    const float inv = 1.0f / l_run;
+    u16* op = O + (long long)b * o_bs + (long long)q_row * ldo + h * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16 hv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = T::from_f32(o_acc[t][4 * g + e] * inv);
+        uint2 pk;
+        pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+        pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+        *reinterpret_cast<uint2*>(op + t * 32 + 8 * g + 4 * hi) = pk;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Cross-attention kernel (Lk <= 96: the 77-token text context, reference attention.py:189-216 with context != x).
 // The whole K [Lk][64] and V^T [64][Lk] of one (batch, head) fit in 26 KB of LDS: they are staged ONCE per workgroup,
 // which then walks `qpb` consecutive 128-query blocks with no further barrier; all keys sit in one tile, so the softmax
@@ -456,13 +664,17 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const u16* __restric
 }
 
 int g_attn_variant = 2;
+int g_attn3_min_lq = 512;   // (env DBIR_ATTN3_MIN_LQ at load time: A/B of the dispatch threshold)
 
 }  // namespace
 
 // A/B switch (dbir_set_option): 2 = default (cross kernel for Lk <= 96, generic otherwise), 3 = generic kernel always,
-// 4 / 5 / 6 = default dispatch with the generic kernel's pre-round-4 softmax (FOLD = false) compiled for 4 / 3 / default resident
+// 8 = the 8-wave attn3_kernel for long self-attentions (experiment, slower); 4 / 5 / 6 = default dispatch with the generic kernel's pre-round-4 softmax (FOLD = false) compiled for 4 / 3 / default resident
 // waves per SIMD; 2 and 3 run the FOLD form (scale folded into Q, running maximum as the score MFMA's C operand, row sum by v_dot2)
-void dbir_attention_set_variant(int v) { g_attn_variant = v; }
+void dbir_attention_set_variant(int v) {
+  if (v >= 1000) g_attn3_min_lq = v - 1000;   // 1000 + n: threshold of the 8-wave kernel (rows of Q), variant unchanged
+  else g_attn_variant = v;
+}
 
 extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, long long ldq, const void* K,
                               long long k_bstride, long long ldk, const void* Vt, long long vt_bstride,
@@ -500,6 +712,19 @@ extern "C" int dbir_attention(int dtype, const void* Q, long long q_bstride, lon
     return DBIR_OK;
   }
   DBIR_CHECK_ARG((long long)cdiv(Lq, 128) * B * H < 2147483647LL, "dbir_attention: grid too large");
+  // round 6 experiment, OFF by default (variant 8 = on): the 8-wave kernel whose wave groups alternate matrix / softmax phases —
+  // measured 0.65x of attn2 (profiles/r6_attn3_ab.txt)
+  if (g_attn_variant == 8 && Lq >= g_attn3_min_lq && Lk >= 256 && (long long)cdiv(Lq, 256) * B * H >= 256) {
+    const dim3 grid3((unsigned)(cdiv(Lq, 256) * B * H));
+    if (dtype == DBIR_F16)
+      hipLaunchKernelGGL((attn3_kernel<F16>), grid3, dim3(512), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K, k_bstride, ldk,
+                         (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
+    else
+      hipLaunchKernelGGL((attn3_kernel<BF16>), grid3, dim3(512), 0, s, (const u16*)Q, q_bstride, ldq, (const u16*)K, k_bstride, ldk,
+                         (const u16*)Vt, vt_bstride, ldvt, (u16*)O, o_bstride, ldo, H, Lq, Lk, sl2);
+    DBIR_CHECK_LAUNCH("dbir_attention(attn3)");
+    return DBIR_OK;
+  }
   const dim3 grid1((unsigned)(cdiv(Lq, 128) * B * H));
 #define ATTN2_LAUNCH(TT, OCC, ...)                                                                                     \
   hipLaunchKernelGGL((attn2_kernel<TT, OCC, ##__VA_ARGS__>), grid1, dim3(256), 0, s, (const u16*)Q, q_bstride, ldq,    \
