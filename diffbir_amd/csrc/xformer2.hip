@@ -206,8 +206,11 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     }
   };
   // ---- GEGLU projection of one chunk: K = C, 4 row blocks x (value, gate); ring period = 5 k-steps
-  auto f1 = [&]() __attribute__((always_inline)) {
+  auto f1 = [&](int c) __attribute__((always_inline)) {
     const char* ap = smem + (4 * rg) * KS * 1024 + x2opq(lane16);
+    // the chunk's bias (hidden units 4 lg .. + 3 of this wave's 16, value | gate) = the C operand of the first MFMAs
+    const f32x4* bl = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(b1l) + (c * CG + cg) * 128 + x2opq(lg * 16));
+    const f32x4 bq[2] = {bl[0], bl[4]};
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) xa[rb] = *reinterpret_cast<const vec8*>(ap + rb * KS * 1024);
     x2_for<0, KS>([&](auto ks_) __attribute__((always_inline)) {
@@ -226,8 +229,7 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
         for (int rb = 0; rb < 4; ++rb) {
           const vec8 xf = (ks & 1) ? xb[rb] : xa[rb];
           if constexpr (ks == 0) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            gacc[rb][nb] = T::mfma16(wq[slot], xf, z);
+            gacc[rb][nb] = T::mfma16(wq[slot], xf, bq[nb]);
           } else {
             gacc[rb][nb] = T::mfma16(wq[slot], xf, gacc[rb][nb]);
           }
@@ -239,16 +241,14 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
       X2_WP_ADV(2);
     });
   };
-  // ---- g = (value + b) * gelu(gate + b) of the chunk whose projection this wave has just finished -> chunk image gbw
-  auto gelu = [&](int c, char* gbw) __attribute__((always_inline)) {
-    const f32x4* bl = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(b1l) + (c * CG + cg) * 128 + x2opq(lg * 16));
-    const f32x4 bq0 = bl[0], bq1 = bl[4];
+  // ---- g = value * gelu(gate) (biases included by the projection) of the chunk this wave has just finished -> chunk image gbw
+  auto gelu = [&](char* gbw) __attribute__((always_inline)) {
     char* const gbo = gbw + (4 * rg) * GK * 1024 + cg * 512 + x2opq(lanew);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (gacc[rb][0][e] + bq0[e]) * gelu_sp(gacc[rb][1][e] + bq1[e]);
+      for (int e = 0; e < 4; ++e) v[e] = gacc[rb][0][e] * gelu_sp(gacc[rb][1][e]);
       uint2 pk;
       pk.x = T::pack2(v[0], v[1]);
       pk.y = T::pack2(v[2], v[3]);
@@ -596,14 +596,14 @@ __global__ __launch_bounds__(X2NT) void xf2_tail_kernel(const Xf2Params p) {
     // every wave: [projection of chunk c | barrier | GELU of chunk c, output projection of chunk c - 1 | barrier] — group 1 one
     // barrier behind group 0, so that on every SIMD one wave multiplies a projection while its partner does GELU arithmetic
     if (grp) x2barrier();
-    f1();
+    f1(0);
     x2barrier();
-    gelu(0, gb0);
+    gelu(gb0);
     x2barrier();
     for (int c = 1; c < NCH; ++c) {
-      f1();
+      f1(c);
       x2barrier();
-      gelu(c, gb0 + (c & 1) * G::GB_BYTES);
+      gelu(gb0 + (c & 1) * G::GB_BYTES);
       f2(gb0 + ((c - 1) & 1) * G::GB_BYTES);
       x2barrier();
     }
