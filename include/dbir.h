@@ -45,10 +45,13 @@ int dbir_abi_version(void);
 /* Process-wide tuning / A-B switches (never needed for correctness): DBIR_OPT_ATTN_VARIANT 2 (default) = LDS-resident
  * cross-attention kernel for Lk <= 96 + generic flash kernel otherwise, 3 = generic flash kernel for every shape, 4 / 5 =
  * the generic kernel's pre-round-4 softmax compiled for 4 / 3 resident waves per SIMD, 6 = pre-round-4 softmax (scale and
- * running maximum applied per score by a v_fma, f32 row sum) at the default register budget. */
+ * running maximum applied per score by a v_fma, f32 row sum) at the default register budget, 8 = long self-attentions on the 8-wave
+ * attn3_kernel whose wave groups alternate matrix / softmax phases (round-6 experiment, measured 0.65x: profiles/r6_attn3_ab.txt);
+ * 1000 + n = attn3's query-row threshold. */
 #define DBIR_OPT_ATTN_VARIANT 1
 /* DBIR_OPT_XF_VARIANT: weight staging schedule of dbir_xf_head / dbir_xf_tail — 1 (default) = the two wave groups stage
- * their shares of a tile at opposite ends of the tile's MFMAs, 0 = every wave stages first (A/B). */
+ * their shares of a tile at opposite ends of the tile's MFMAs, 0 = every wave stages first (A/B).  First-generation kernels only
+ * (csrc/xformer.hip); the second-generation kernels (csrc/xformer2.hip) have no staging to schedule. */
 #define DBIR_OPT_XF_VARIANT 2
 int dbir_set_option(int key, int value);
 
